@@ -1,0 +1,108 @@
+/*
+ * pareben_hip.h -- C ABI of libpareben_hip.so: the MI355X (gfx950) replacement for the part of
+ * parEBEN that CrossValidate() farms out through foreach: the nFolds x alpha x lambda grid of
+ * EBelasticNet fits plus the per-fold scoring.
+ *
+ * Plain pointers and sizes only.  All matrices are column-major doubles exactly as R passes
+ * them through .C()/.Call() (as.double(BASIS)); all index vectors are 32-bit ints; fold ids are
+ * 1-based like R's.  Every function returns 0 on success or a negative PAREBEN_E* code; none
+ * calls exit() or the R API, so they may be called from any host language (R .Call glue, ctypes,
+ * cgo ...).  INTEGRATION.md shows the reference-side bindings.
+ *
+ * What each entry point replaces in the reference (paths relative to the parEBEN tree):
+ *   pareben_cv_grid / pareben_ctx_run   the foreach over grid rows in R/CrossValidate.R:66-70 and
+ *                                       :88-92, i.e. R/TestModel.R:6-39 (fold split, fit, score),
+ *                                       EBEN_orig/R/EBelasticNet.Gaussian.R:39-66 (.C marshalling,
+ *                                       non-zero-row filter) and R/GetModelError.R:6-59
+ *   pareben_fit_gaussian                .C("elasticNetLinearNeMainEff", ...) in
+ *                                       EBEN_orig/R/EBelasticNet.Gaussian.R:39-51, i.e.
+ *                                       EBEN_orig/src/elasticNetLinearNeMainEff.c:55
+ */
+#ifndef PAREBEN_HIP_H
+#define PAREBEN_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PAREBEN_OK            0
+#define PAREBEN_EINVAL       -1   /* bad argument                                   */
+#define PAREBEN_EHIP         -2   /* HIP runtime error (see pareben_last_error)     */
+#define PAREBEN_ENOMEM       -3   /* device workspace does not fit                  */
+#define PAREBEN_EUNSUPPORTED -4   /* prior/epis combination not built yet           */
+
+#define PAREBEN_PRIOR_GAUSSIAN 0
+#define PAREBEN_PRIOR_BINOMIAL 1
+
+/* per-fit status bits written to status[] */
+#define PAREBEN_ST_OVERFLOW 1     /* active set reached the workspace capacity       */
+#define PAREBEN_ST_CHOLESKY 2     /* Hessian not positive definite                   */
+#define PAREBEN_ST_STALE    4     /* reference's stale-slot delete path was taken    */
+#define PAREBEN_ST_ABORT    8     /* fit stopped early; its score is not meaningful  */
+
+/* number of int64 counters per fit in counters[] (order: n_outer, n_inner, n_add, n_del,
+ * n_reest, n_fullstat, sum_m_action, sum_m_full, sum_m2_full, m_final, m_max, status) */
+#define PAREBEN_NCOUNTERS 12
+
+typedef struct pareben_ctx pareben_ctx;
+
+/* Library / device probes. */
+const char *pareben_version(void);
+const char *pareben_last_error(void);
+int pareben_device_count(void);
+
+/*
+ * Stage one CV problem in HBM: BASIS (n x p, column-major), Target (n), fold ids (1..n_folds,
+ * what R/AssignToFolds.R:6-19 returns).  epis: 0 = main effects, 1 = add pairwise columns.
+ * max_active <= 0 picks the default active-set capacity min(p, 1e7/p, 2048) (the reference's
+ * basisMax, elasticNetLinearNeMainEff.c:68-69, bounded).  The context owns every device buffer.
+ */
+int pareben_ctx_create(pareben_ctx **out, int device,
+                       const double *basis, int n, int p, const double *target,
+                       const int32_t *fold_id, int n_folds,
+                       int prior, int epis, int max_active);
+
+/*
+ * Evaluate n_cells (alpha, lambda) cells x n_folds folds on the context's GPU.
+ *   fold_err [n_cells * n_folds], cell-major: gaussian -> held-out SSE (R/GetModelError.R:30-31),
+ *                                             binomial -> mean held-out log-likelihood (:55)
+ *   status   [n_cells * n_folds] or NULL
+ *   counters [n_cells * n_folds * PAREBEN_NCOUNTERS] or NULL
+ * Inputs are already resident; the call launches the per-fold preparation kernels (row split,
+ * column statistics, Gram matrices) and the fit kernel on the context's stream, then copies the
+ * small result arrays back.
+ */
+int pareben_ctx_run(pareben_ctx *ctx, int n_cells, const double *alpha, const double *lambda,
+                    double *fold_err, int32_t *status, int64_t *counters);
+
+/* Timings of the last pareben_ctx_run, measured with HIP events on the context's stream:
+ * ms[0] preparation kernels, ms[1] fit kernel, ms[2] whole call including result copies. */
+int pareben_ctx_last_timing(pareben_ctx *ctx, double ms[3]);
+
+/* Geometry of the last launch: info[0] workgroups, info[1] threads per workgroup,
+ * info[2] active-set capacity, info[3] workspace bytes per workgroup (low 31 bits in KiB). */
+int pareben_ctx_launch_info(pareben_ctx *ctx, int64_t info[4]);
+
+int pareben_ctx_destroy(pareben_ctx *ctx);
+
+/* One-shot convenience: create + run + destroy. */
+int pareben_cv_grid(const double *basis, int n, int p, const double *target,
+                    const int32_t *fold_id, int n_folds,
+                    const double *alpha, const double *lambda, int n_cells,
+                    int epis, int prior, int device,
+                    double *fold_err, int32_t *status, int64_t *counters);
+
+/*
+ * One fit on all rows, same argument tuple as the reference's .C entry
+ * (EBEN_orig/R/EBelasticNet.Gaussian.R:39-51): Beta is K x 4 column-major
+ * (loc1, loc2, beta, posterior variance), outputs written in place.
+ */
+int pareben_fit_gaussian(const double *basis, const double *target, double lambda, double alpha,
+                         double *Beta, double *wald, double *intercept, int n, int k,
+                         int verbose, double *residual, int device, int64_t *counters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,561 @@
+/*
+ * eben_gm.c -- oracle: Gaussian main-effect EBEN fit ("Gm"), a CPU restatement of the
+ * algorithm in EBEN_orig/src/elasticNetLinearNeMainEff.c.
+ *
+ * TEST INFRASTRUCTURE ONLY (see eben_oracle.h).  Written from the algorithm, with its own
+ * data structures (one dense row-major arena for the feature x basis cache instead of row
+ * pointers, 0-based indices, a state struct), keeping the reference's arithmetic order
+ * (sequential sums, separate multiply and add: build with -ffp-contract=off) and every quirk
+ * that changes results.  Each routine cites the lines it follows.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include "eben_oracle.h"
+#include "eben_linalg.h"
+#ifdef EBEN_TRACE
+#include <stdio.h>
+#define TRACE(...) fprintf(stderr, __VA_ARGS__)
+#else
+#define TRACE(...)
+#endif
+
+enum { ACT_NONE = -10, ACT_REEST = 0, ACT_ADD = 1, ACT_DEL = -1, ACT_TERM = 10 };
+
+typedef struct {
+    int N, K, cap;
+    const double *X, *y;
+    double lambda, alpha;
+    double *scale;             /* K   column norms (1 if zero)                    */
+    double *t;                 /* N   targets = y - intercept                     */
+    int *used, M;              /* active set, feature ids 0-based                 */
+    int *unused, n_unused;     /* visiting order of the inactive set (Q5)         */
+    double *A, *mu, *gam;      /* cap                                             */
+    double *Sig, *SigNew, *H;  /* cap*cap, column-major, leading dim = current M  */
+    double *Phi;               /* N*cap, column l = x_used[l] / scale             */
+    double *BP;                /* cap*K arena, row l: x_i . Phi_l / scale_i       */
+    double *bt;                /* K  x_i . t / scale_i                            */
+    double *Sin, *Qin, *Sout, *Qout, *dml, *aroot;
+    int *act, *todo;
+    double beta;
+    eben_counters c;
+} gm;
+
+/* ---- initial model + inactive list, :976-1108.  Q1: the "least correlated" search never
+ * fires (|proj| < 0 is false), so the first basis is always column 0. */
+static void gm_initialise(gm *s, int first)
+{
+    const int N = s->N, K = s->K;
+    if (first) {
+        s->M = 1;
+        s->used[0] = 0;
+        double r = 1 / s->scale[0];
+        for (int h = 0; h < N; h++) s->Phi[h] = s->X[h] * r;
+        s->beta = 1 / (var_unbiased(s->t, N) * 0.01 + 1e-10);
+        double p = dot_seq(N, s->Phi, s->Phi) * s->beta;
+        double q = dot_seq(N, s->Phi, s->t) * s->beta;
+        s->A[0] = p * p / (q * q - p);
+        if (s->A[0] < 0) s->A[0] = 1e2;
+        if (s->A[0] > 1e2) s->A[0] = 1e2;
+    }
+    int kk = 0;
+    for (int i = 0; i < K; i++) {
+        int is_used = 0;
+        for (int j = 0; j < s->M; j++) if (s->used[j] == i) is_used = 1;
+        if (!is_used) s->unused[kk++] = i;
+    }
+    s->n_unused = K - s->M;
+}
+
+/* ---- cache x_i.Phi_l/scale_i and x_i.t/scale_i, :1144-1201 */
+static void gm_cache(gm *s)
+{
+    const int N = s->N, K = s->K, M = s->M;
+    for (int i = 0; i < K; i++) {
+        const double *x = s->X + (size_t)i * N;
+        for (int l = 0; l < M; l++) {
+            const double *ph = s->Phi + (size_t)l * N;
+            double z = 0;
+            for (int h = 0; h < N; h++) z = z + ph[h] * x[h];
+            s->BP[(size_t)l * K + i] = z / s->scale[i];
+        }
+        double zt = 0;
+        for (int h = 0; h < N; h++) zt = zt + x[h] * s->t[h];
+        s->bt[i] = zt / s->scale[i];
+    }
+}
+
+/* S_out/Q_out of the active features, :1328-1338 and :666-671 */
+static void gm_refresh_out(gm *s)
+{
+    memcpy(s->Sout, s->Sin, sizeof(double) * s->K);
+    memcpy(s->Qout, s->Qin, sizeof(double) * s->K);
+    for (int i = 0; i < s->M; i++) {
+        int f = s->used[i];
+        s->Sout[f] = s->A[i] * s->Sin[f] / (s->A[i] - s->Sin[f]);
+        s->Qout[f] = s->A[i] * s->Qin[f] / (s->A[i] - s->Sin[f]);
+    }
+}
+
+/* ---- full statistics, :1209-1341.  Q3: gamma[0] is not refreshed here. */
+static void gm_fullstat(gm *s, int very_first)
+{
+    const int N = s->N, K = s->K, M = s->M;
+    if (very_first) {
+        s->H[0] = dot_seq(N, s->Phi, s->Phi) * s->beta + s->A[0];
+        s->Sig[0] = 1 / s->H[0];
+    }
+    double *pt = (double *)calloc(M, sizeof(double));
+    double *bv = (double *)calloc(M, sizeof(double));
+    for (int l = 0; l < M; l++) pt[l] = dot_seq(N, s->Phi + (size_t)l * N, s->t);
+    /* mu = beta * Sig * pt, column-sweep order of a reference dgemv('N') */
+    for (int i = 0; i < M; i++) s->mu[i] = 0;
+    for (int j = 0; j < M; j++) {
+        double tj = pt[j];
+        for (int i = 0; i < M; i++) s->mu[i] += tj * s->Sig[(size_t)j * M + i];
+    }
+    for (int i = 0; i < M; i++) s->mu[i] *= s->beta;
+    for (int i = 1; i < M; i++) s->gam[i] = 1 - s->Sig[(size_t)i * M + i] * s->A[i];
+
+    for (int i = 0; i < K; i++) {
+        for (int j = 0; j < M; j++) {
+            double a = 0;
+            for (int p = 0; p < M; p++) a = a + s->BP[(size_t)p * K + i] * s->Sig[(size_t)j * M + p];
+            bv[j] = a;
+        }
+        double quad = 0, bm = 0;
+        for (int j = 0; j < M; j++) quad = quad + bv[j] * s->BP[(size_t)j * K + i];
+        for (int p = 0; p < M; p++) bm = bm + s->BP[(size_t)p * K + i] * s->mu[p];
+        s->Sin[i] = s->beta - s->beta * quad * s->beta;
+        s->Qin[i] = s->beta * (s->bt[i] - bm);
+    }
+    gm_refresh_out(s);
+    free(pt); free(bv);
+    s->c.n_fullstat++; s->c.sum_m_full += M; s->c.sum_m2_full += (int64_t)M * M;
+}
+
+/* ---- per-feature marginal-likelihood change and action choice, :1372-1582.
+ * Returns the arg-max feature; *best gets the max.  Visiting order: active set in `used`
+ * order, then inactive in `unused` order, strict '>' (Q5); Q15: only Gm sets any_add. */
+static int gm_delta_ml(gm *s, int *any_del, double *best, double residual, double varY,
+                       int iter, int i_iter)
+{
+    const int K = s->K, M = s->M, N = s->N;
+    const double l1 = s->lambda * s->alpha, l2 = s->lambda * (1 - s->alpha);
+    int any_add = 0, prio_add = 0, prio_del = 0;
+    *any_del = 0;
+    if (M < 10) { prio_add = 1; prio_del = 0; }
+    if (M > 100 || M >= N || residual <= varY * 0.1) { prio_add = 0; prio_del = 1; }
+    for (int i = 0; i < K; i++) s->act[i] = ACT_NONE;
+    double dmax = 0; int imax = 0;
+
+    for (int i = 0; i < M; i++) {
+        int f = s->used[i];
+        double so = s->Sout[f], qo = s->Qout[f];
+        s->dml[f] = 0;
+        double a = so - qo * qo + 2 * l1 + l2;
+        double b = (so + l2) * (so + 4 * l1 + l2);
+        double g = 2 * l1 * (so + l2) * (so + l2);
+        double d = b * b - 4 * a * g;
+        if (a < 0 && d > 0) {
+            double r = (-b - sqrt(d)) / (2 * a);
+            double L = (log(r / (r + so + l2)) + pow(qo, 2) / (r + so + l2)) * 0.5 - l1 / r;
+            if (L > 0) {
+                s->aroot[f] = r + l2;
+                s->act[f] = ACT_REEST;
+                double o = s->A[i] - l2;
+                s->dml[f] = 0.5 * (log(r * (o + so + l2) / (o * (r + so + l2))) +
+                                   qo * qo * (1 / (r + so + l2) - 1 / (o + so + l2))) -
+                            l1 * (1 / r - 1 / o);
+            }
+        } else if (M > 1) {
+            *any_del = 1;
+            s->act[f] = ACT_DEL;
+            double o = s->A[i] - l2;
+            double L = (log(o / (o + so + l2)) + pow(qo, 2) / (o + so + l2)) * 0.5 - l1 / o;
+            s->dml[f] = -L;
+        }
+        if (s->dml[f] > dmax) { imax = f; dmax = s->dml[f]; }
+    }
+    for (int i = 0; i < s->n_unused; i++) {
+        int f = s->unused[i];
+        double so = s->Sout[f], qo = s->Qout[f];
+        s->dml[f] = 0;
+        double a = so - qo * qo + 2 * l1 + l2;
+        double b = (so + l2) * (so + l2 + 4 * l1);
+        double g = 2 * l1 * (so + l2) * (so + l2);
+        double d = b * b - 4 * a * g;
+        if (a < 0 && d > 0) {
+            double r = (-b - sqrt(d)) / (2 * a);
+            double L = (log(r / (r + so + l2)) + pow(qo, 2) / (r + so + l2)) * 0.5 - l1 / r;
+            if (L > 0) {
+                s->aroot[f] = r + l2;
+                s->act[f] = ACT_ADD;
+                s->dml[f] = L;
+                any_add = 1;
+            }
+        }
+        if (s->dml[f] > dmax) { imax = f; dmax = s->dml[f]; }
+    }
+
+    if ((any_add && prio_add) || (*any_del && prio_del)) {
+        for (int i = 0; i < K; i++) {
+            if (s->act[i] == ACT_REEST) s->dml[i] = 0;
+            else if (s->act[i] == ACT_DEL) { if (any_add && prio_add && !prio_del) s->dml[i] = 0; }
+            else if (s->act[i] == ACT_ADD) { if (*any_del && prio_del && !prio_add) s->dml[i] = 0; }
+        }
+        dmax = 0; imax = 0;
+        for (int i = 0; i < K; i++) if (s->dml[i] > dmax) { imax = i; dmax = s->dml[i]; }
+    }
+    if ((!any_add && iter == 1 && i_iter < 10) || (!any_add && residual >= varY * 0.95)) {
+        for (int i = 0; i < K; i++) if (s->act[i] == ACT_DEL) s->dml[i] = 0;
+        dmax = 0; imax = 0;
+        for (int i = 0; i < K; i++) if (s->dml[i] > dmax) { imax = i; dmax = s->dml[i]; }
+    }
+    *best = dmax;
+    return imax;
+}
+
+/* ---- add feature nu with precision newA, :1585-1723 and :613-627.  phi = x_nu/scale_nu. */
+static void gm_add(gm *s, int nu, double newA, const double *phi)
+{
+    const int N = s->N, K = s->K, M = s->M, M1 = s->M + 1;
+    double *row = s->BP + (size_t)M * K;          /* new cache row */
+    double *bb = (double *)calloc(K, sizeof(double));
+    double *tmp = (double *)calloc(M, sizeof(double));
+    double *tp = (double *)calloc(M, sizeof(double));
+    double *si = (double *)calloc(M, sizeof(double));
+    for (int i = 0; i < K; i++) {
+        const double *x = s->X + (size_t)i * N;
+        double z = 0;
+        for (int h = 0; h < N; h++) z = z + x[h] * phi[h];
+        row[i] = z / s->scale[i];
+        bb[i] = s->beta * row[i];
+    }
+    for (int i = 0; i < M; i++) tmp[i] = dot_seq(N, s->Phi + (size_t)i * N, phi);
+    for (int i = 0; i < M; i++) tmp[i] *= s->beta;
+    for (int i = 0; i < M; i++) tp[i] = dot_seq(M, s->Sig + (size_t)i * M, tmp);
+    s->A[M] = newA;
+    memcpy(s->Phi + (size_t)M * N, phi, sizeof(double) * N);
+    double sii = 1.0 / (newA + s->Sin[nu]);
+    double mui = sii * s->Qin[nu];
+    for (int i = 0; i < M; i++) s->mu[i] += -mui * tp[i];
+    s->mu[M] = mui;
+    for (int i = 0; i < M; i++) si[i] = tp[i] * -sii;
+    for (int i = 0; i < M; i++)
+        for (int j = 0; j < M; j++) {
+            double tau = -si[i] * tp[j];
+            s->SigNew[(size_t)j * M1 + i] = s->Sig[(size_t)j * M + i] + tau;
+        }
+    for (int i = 0; i < M; i++) {
+        s->SigNew[(size_t)M * M1 + i] = si[i];
+        s->SigNew[(size_t)i * M1 + M] = si[i];
+    }
+    s->SigNew[(size_t)M * M1 + M] = sii;
+    for (int i = 0; i < K; i++) {
+        double a = 0;
+        for (int j = 0; j < M; j++) a = a + s->BP[(size_t)j * K + i] * tp[j];
+        double mc = bb[i] - s->beta * a;
+        s->Sin[i] = s->Sin[i] - mc * mc * sii;
+        s->Qin[i] = s->Qin[i] - mui * mc;
+    }
+    TRACE("    add nu=%d newA=%.15g sii=%.15g mui=%.15g tp0=%.15g tmp0=%.15g Sin=%.15g Qin=%.15g mu0=%.15g\n", nu, newA, sii, mui, tp[0], tmp[0], s->Sin[nu], s->Qin[nu], s->mu[0]);
+    s->used[M] = nu;
+    s->n_unused--;
+    for (int i = 0; i < s->n_unused; i++)          /* swap-removal, Q5 */
+        if (s->unused[i] == nu) s->unused[i] = s->unused[s->n_unused];
+    s->M = M1;
+    free(bb); free(tmp); free(tp); free(si);
+}
+
+/* ---- delete active slot jj (feature nu), :1725-1822 and :640-651.  Q2: the removed weight is
+ * truncated to an int before the mean and Q_in down-dates. */
+static void gm_delete(gm *s, int jj, int nu)
+{
+    const int N = s->N, K = s->K, M = s->M, last = s->M - 1;
+    double *Sg = s->Sig;
+    double sjj = Sg[(size_t)jj * M + jj];
+    s->A[jj] = s->A[last];
+    memcpy(s->Phi + (size_t)jj * N, s->Phi + (size_t)last * N, sizeof(double) * N);
+    int mujj = (int)s->mu[jj];
+    for (int i = 0; i < M; i++) s->mu[i] = s->mu[i] - mujj * Sg[(size_t)jj * M + i] / sjj;
+    s->mu[jj] = s->mu[last];
+    double *T = (double *)calloc((size_t)M * M, sizeof(double));
+    for (int i = 0; i < M; i++)
+        for (int j = 0; j < M; j++)
+            T[(size_t)j * M + i] = Sg[(size_t)j * M + i] - Sg[(size_t)jj * M + i] / sjj * Sg[(size_t)jj * M + j];
+    for (int i = 0; i < last; i++)
+        for (int j = 0; j < last; j++) s->SigNew[(size_t)j * last + i] = T[(size_t)j * M + i];
+    if (jj != last) {
+        for (int i = 0; i < last; i++) s->SigNew[(size_t)jj * last + i] = T[(size_t)last * M + i];
+        T[(size_t)jj * M + last] = T[(size_t)M * M - 1];
+        for (int c = 0; c < last; c++) s->SigNew[(size_t)c * last + jj] = T[(size_t)c * M + last];
+    }
+    for (int i = 0; i < K; i++) {
+        double a = 0;
+        for (int j = 0; j < M; j++) a = a + s->BP[(size_t)j * K + i] * Sg[(size_t)jj * M + j];
+        s->Sin[i] = s->Sin[i] + pow(s->beta * a, 2) / sjj;
+        s->Qin[i] = s->Qin[i] + s->beta * a * mujj / sjj;
+    }
+    if (jj != last) memcpy(s->BP + (size_t)jj * K, s->BP + (size_t)last * K, sizeof(double) * K);
+    s->used[jj] = s->used[last];
+    s->n_unused++;
+    s->unused[s->n_unused - 1] = nu;
+    s->M = last;
+    free(T);
+}
+
+/* ---- re-estimate the precision of active slot jj, :553-596 */
+static void gm_reestimate(gm *s, int jj, double newA)
+{
+    const int K = s->K, M = s->M;
+    double *Sg = s->Sig;
+    double oldA = s->A[jj];
+    s->A[jj] = newA;
+    double dinv = 1.0 / (newA - oldA);
+    double kappa = 1.0 / (Sg[(size_t)jj * M + jj] + dinv);
+    double mujj = s->mu[jj];
+    double f = -mujj * kappa;
+    for (int i = 0; i < M; i++) s->mu[i] += f * Sg[(size_t)jj * M + i];
+    for (int i = 0; i < M; i++)
+        for (int j = 0; j < M; j++)
+            s->SigNew[(size_t)j * M + i] = Sg[(size_t)j * M + i] - kappa * Sg[(size_t)jj * M + i] * Sg[(size_t)jj * M + j];
+    for (int i = 0; i < K; i++) {
+        double a = 0;
+        for (int j = 0; j < M; j++) a = a + s->BP[(size_t)j * K + i] * Sg[(size_t)jj * M + j];
+        s->Sin[i] = s->Sin[i] + pow(s->beta * a, 2) * kappa;
+        s->Qin[i] = s->Qin[i] + s->beta * mujj * kappa * a;
+    }
+}
+
+/* ---- H = beta Phi'Phi + diag(A); Sig = H^-1; mu = beta Sig Phi't, :1841-1921 */
+static void gm_final_update(gm *s)
+{
+    const int N = s->N, M = s->M;
+    for (int j = 0; j < M; j++)
+        for (int i = 0; i < M; i++)
+            s->H[(size_t)j * M + i] = dot_seq(N, s->Phi + (size_t)i * N, s->Phi + (size_t)j * N) * s->beta;
+    for (int i = 0; i < M; i++) s->H[(size_t)i * M + i] += s->A[i];
+    memcpy(s->Sig, s->H, sizeof(double) * M * M);
+    if (chol_inverse_upper(s->Sig, M)) s->c.status |= 2;   /* Q11: carry on regardless */
+    double *pt = (double *)calloc(M, sizeof(double));
+    for (int l = 0; l < M; l++) pt[l] = dot_seq(N, s->Phi + (size_t)l * N, s->t);
+    for (int i = 0; i < M; i++) s->mu[i] = 0;
+    for (int j = 0; j < M; j++) {
+        double tj = pt[j];
+        for (int i = 0; i < M; i++) s->mu[i] += tj * s->Sig[(size_t)j * M + i];
+    }
+    for (int i = 0; i < M; i++) s->mu[i] *= s->beta;
+    free(pt);
+}
+
+/* ---- one call of the inner routine, :248-809.  Returns sum_i Csum_i and Csum.y through
+ * cs/csy so the caller can update the intercept (:172-188): the N x N matrix
+ * C^-1 = beta I - beta^2 Phi Sig Phi' is not formed, its column sums are. */
+static int gm_inner(gm *s, int iter, double residual, double varY, double *cs, double *csy)
+{
+    const int N = s->N, K = s->K;
+    gm_initialise(s, iter <= 1);
+    memset(s->gam, 0, sizeof(double) * (s->cap + 1));   /* the reference callocs gamma per call (:344) */
+    int initial = s->used[0];
+    int ini_removed = iter <= 1 ? 0 : 1;
+    gm_cache(s);
+    int i_iter = 0;
+    gm_fullstat(s, iter == 1);
+
+    int sel = ACT_NONE, jj = -1, n_todo = 0, any_del = 0, last_it = 0;
+    const int it_max = iter == 1 ? 10 : 100;
+    double *phi = (double *)calloc(N, sizeof(double));
+    double *e = (double *)calloc(N, sizeof(double));
+
+    while (!last_it) {
+        i_iter++;
+        s->c.n_inner++;
+        double best;
+        int nu = gm_delta_ml(s, &any_del, &best, residual, varY, iter, i_iter);
+        int worthwhile;
+        if (sel == ACT_TERM && !ini_removed && s->M > 1) nu = -1;
+        if (nu == -1 && ini_removed) {
+            worthwhile = 0; sel = ACT_TERM;
+        } else if (nu == -1 && !ini_removed && s->M > 1) {      /* forced removal, :437-446 */
+            worthwhile = 1;
+            nu = initial;
+            s->act[nu] = ACT_DEL;
+            n_todo = 1; s->todo[0] = initial;
+            ini_removed = 1;
+            sel = ACT_DEL;
+        } else {
+            worthwhile = 1;
+            double cutoff = best * (s->act[nu] == ACT_ADD ? 0.9 : 1.0);
+            if (cutoff < 0.001) cutoff = 0.001;
+            n_todo = 0;
+            for (int i = 0; i < K; i++) if (s->dml[i] >= cutoff) s->todo[n_todo++] = i;
+            if (s->act[nu] == ACT_DEL && n_todo > 1) n_todo = 1;
+            if (n_todo == 0) worthwhile = 0;
+        }
+        if (!worthwhile) sel = ACT_TERM;
+        if (worthwhile) {
+            for (int u = 0; u < n_todo; u++) {
+                nu = s->todo[u];
+                sel = s->act[nu];
+                double newA = s->aroot[nu];
+                if (sel == ACT_REEST || sel == ACT_DEL) {
+                    int found = 0;
+                    for (int i = 0; i < s->M; i++) if (s->used[i] == nu) { jj = i; found = 1; break; }
+                    if (!found) {            /* reference would use a stale jj (UB); flag it */
+                        s->c.status |= 4;
+                        if (jj < 0 || jj >= s->M) { free(phi); free(e); return 1; }
+                    }
+                }
+                double r = 1 / s->scale[nu];
+                for (int h = 0; h < N; h++) phi[h] = s->X[(size_t)nu * N + h] * r;
+                if (sel == ACT_REEST && fabs(log(newA) - log(s->A[jj])) <= 1e-3 && any_del == 0)
+                    sel = ACT_TERM;
+                int upd = 0;
+                if (sel == ACT_REEST) {
+                    s->c.n_reest++; s->c.sum_m_action += s->M;
+                    gm_reestimate(s, jj, newA);
+                    upd = 1;
+                } else if (sel == ACT_ADD) {
+                    if (s->M + 1 > s->cap) { s->c.status |= 1; free(phi); free(e); return 1; }
+                    s->c.n_add++; s->c.sum_m_action += s->M;
+                    gm_add(s, nu, newA, phi);
+                    upd = 1;
+                } else if (sel == ACT_DEL) {
+                    s->c.n_del++; s->c.sum_m_action += s->M;
+                    gm_delete(s, jj, nu);
+                    upd = 1;
+                }
+                if (upd) {
+                    gm_refresh_out(s);
+                    memcpy(s->Sig, s->SigNew, sizeof(double) * s->M * s->M);
+                    for (int i = 0; i < s->M; i++) s->gam[i] = 1 - s->A[i] * s->Sig[(size_t)i * s->M + i];
+                    if (s->M > s->c.m_max) s->c.m_max = s->M;
+                }
+            }
+        }
+        if (sel == ACT_TERM || i_iter <= 10 || i_iter % 5 == 0 || n_todo >= 2) {   /* :685-729 */
+            const int M = s->M;
+            for (int h = 0; h < N; h++) e[h] = 0;
+            for (int j = 0; j < M; j++) {
+                double mj = s->mu[j];
+                const double *ph = s->Phi + (size_t)j * N;
+                for (int h = 0; h < N; h++) e[h] += mj * ph[h];
+            }
+            for (int h = 0; h < N; h++) e[h] = s->t[h] + -1.0 * e[h];
+            double ee = dot_seq(N, e, e);
+            double beta_old = s->beta, gsum = 0;
+            for (int i = 0; i < M; i++) gsum = gsum + s->gam[i];
+            s->beta = (N - gsum) / ee;
+            double vt = var_unbiased(s->t, N);
+            if (s->beta > 1e6 / vt) s->beta = 1e6 / vt;
+            double dlb = log(s->beta) - log(beta_old);
+            if (fabs(dlb) > 1e-6) {
+                gm_final_update(s);
+                if (sel != ACT_TERM) gm_fullstat(s, 0);
+            }
+        }
+        TRACE("  it %d.%d M=%d sel=%d ntodo=%d beta=%.15g mu0=%.15g A0=%.15g gam0=%.15g\n", iter, i_iter, s->M, sel, n_todo, s->beta, s->mu[0], s->A[0], s->gam[0]);
+        if (sel == ACT_TERM && ini_removed) last_it = 1;
+        if ((i_iter == it_max && s->M == 1) || i_iter > it_max) last_it = 1;
+        if (i_iter == it_max) sel = ACT_TERM;
+    }
+    /* column sums of C^-1 (:741-781 + :172-187), O(N M + M^2) form */
+    {
+        const int M = s->M;
+        double *c1 = (double *)calloc(M, sizeof(double));
+        double *w = (double *)calloc(M, sizeof(double));
+        for (int l = 0; l < M; l++) { double a = 0; const double *ph = s->Phi + (size_t)l * N; for (int h = 0; h < N; h++) a += ph[h]; c1[l] = a; }
+        for (int j = 0; j < M; j++) for (int i = 0; i < M; i++) w[i] += c1[j] * s->Sig[(size_t)j * M + i];
+        for (int h = 0; h < N; h++) e[h] = 0;
+        for (int j = 0; j < M; j++) { double wj = w[j]; const double *ph = s->Phi + (size_t)j * N; for (int h = 0; h < N; h++) e[h] += wj * ph[h]; }
+        double a = 0, b = 0, b2 = s->beta * s->beta;
+        for (int h = 0; h < N; h++) { double c = s->beta - b2 * e[h]; a = a + c; b = b + c * s->y[h]; }
+        *cs = a; *csy = b;
+        free(c1); free(w);
+    }
+    free(phi); free(e);
+    return 0;
+}
+
+int eben_gm_fit(const double *X, const double *y, int N, int K, double lambda, double alpha,
+                double *Beta, double *wald, double *intercept, double *residual,
+                eben_counters *cnt)
+{
+    gm S; memset(&S, 0, sizeof(S));
+    gm *s = &S;
+    s->N = N; s->K = K; s->X = X; s->y = y; s->lambda = lambda; s->alpha = alpha;
+    int cap = (int)(1e7 / K);                      /* basisMax, :68-69 */
+    if (cap > K) cap = K;
+    s->cap = cap;
+    s->scale = (double *)calloc(K, sizeof(double));
+    for (int i = 0; i < K; i++) {
+        Beta[i] = i + 1; Beta[K + i] = i + 1; Beta[2 * (size_t)K + i] = 0; Beta[3 * (size_t)K + i] = 0;
+        double q = dot_seq(N, X + (size_t)i * N, X + (size_t)i * N);
+        if (q == 0) q = 1;
+        s->scale[i] = sqrt(q);
+    }
+    s->t = (double *)calloc(N, sizeof(double));
+    s->used = (int *)calloc(cap, sizeof(int));
+    s->unused = (int *)calloc(K, sizeof(int));
+    s->A = (double *)calloc(cap + 1, sizeof(double));
+    s->mu = (double *)calloc(cap + 1, sizeof(double));
+    s->gam = (double *)calloc(cap + 1, sizeof(double));
+    s->Sig = (double *)calloc((size_t)cap * cap, sizeof(double));
+    s->SigNew = (double *)calloc((size_t)cap * cap, sizeof(double));
+    s->H = (double *)calloc((size_t)cap * cap, sizeof(double));
+    s->Phi = (double *)calloc((size_t)N * cap, sizeof(double));
+    s->BP = (double *)calloc((size_t)cap * K, sizeof(double));
+    s->bt = (double *)calloc(K, sizeof(double));
+    s->Sin = (double *)calloc(K, sizeof(double)); s->Qin = (double *)calloc(K, sizeof(double));
+    s->Sout = (double *)calloc(K, sizeof(double)); s->Qout = (double *)calloc(K, sizeof(double));
+    s->dml = (double *)calloc(K, sizeof(double)); s->aroot = (double *)calloc(K, sizeof(double));
+    s->act = (int *)calloc(K, sizeof(int)); s->todo = (int *)calloc(K, sizeof(int));
+    s->M = 1;
+
+    double b = 0;
+    for (int i = 0; i < N; i++) b += 1.0 * y[i];
+    b = b / N;
+    const double varT = var_unbiased(y, N);
+    double residvar = 1e10, err = 1000, vk = 1e-30, vk0;
+    int iter = 0, rc = 0;
+    while (iter < 100 && err > 1e-8 && residvar >= varT * 0.01) {       /* :155-197 */
+        iter++;
+        vk0 = vk;
+        for (int i = 0; i < N; i++) s->t[i] = -b + 1.0 * y[i];
+        double cs, csy;
+        rc = gm_inner(s, iter, residvar, varT, &cs, &csy);
+        if (rc) break;
+        b = csy / (cs + 1e-10);
+        vk = 0;
+        for (int i = 0; i < s->M; i++) vk += s->A[i];
+        err = fabs(vk - vk0) / s->M;
+        residvar = 1 / (s->beta + 1e-10);
+    }
+    s->c.n_outer = iter;
+    /* Wald score uses whatever H the last final update left (its own leading dimension) */
+    {
+        const int M = s->M;
+        double w = 0;
+        double *tw = (double *)calloc(M, sizeof(double));
+        for (int i = 0; i < M; i++) tw[i] = dot_seq(M, s->mu, s->H + (size_t)i * M);
+        w = dot_seq(M, tw, s->mu);
+        free(tw);
+        *wald = w;
+        for (int i = 0; i < M; i++) {
+            int f = s->used[i];
+            Beta[2 * (size_t)K + f] = s->mu[i] / s->scale[f];
+            Beta[3 * (size_t)K + f] = s->Sig[(size_t)i * M + i] / (s->scale[f] * s->scale[f]);
+        }
+    }
+    *intercept = b;
+    *residual = 1 / (s->beta + 1e-10);
+    s->c.m_final = s->M;
+    if (s->M > s->c.m_max) s->c.m_max = s->M;
+    if (cnt) *cnt = s->c;
+    free(s->scale); free(s->t); free(s->used); free(s->unused); free(s->A); free(s->mu); free(s->gam);
+    free(s->Sig); free(s->SigNew); free(s->H); free(s->Phi); free(s->BP); free(s->bt);
+    free(s->Sin); free(s->Qin); free(s->Sout); free(s->Qout); free(s->dml); free(s->aroot);
+    free(s->act); free(s->todo);
+    return rc;
+}

@@ -1,0 +1,62 @@
+/*
+ * eben_oracle.h -- CPU restatement of the EBEN fit kernels that parEBEN's CrossValidate()
+ * drives.  TEST INFRASTRUCTURE ONLY: nothing under pareben_amd/ may include, link or call
+ * this; it is the checker for the HIP path (tests/, __graft_entry__.smoke(), bench.py's
+ * cpu_baseline leg).
+ *
+ * Pinning: see oracle/README.md -- real-R outputs stored in the reference tree
+ * (the .RDS files under paper_materials/) and the known answers recorded in SURVEY.md section 10.
+ */
+#ifndef EBEN_ORACLE_H
+#define EBEN_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* per-fit event counters (SURVEY.md 8(d) accounting) */
+typedef struct {
+    int64_t n_outer;      /* outer (intercept) iterations                           */
+    int64_t n_inner;      /* inner iterations, all outer iterations together        */
+    int64_t n_add, n_del, n_reest;
+    int64_t n_fullstat;   /* full S/Q recomputations                                */
+    int64_t sum_m_action; /* sum over add/delete/re-estimate events of M at event   */
+    int64_t sum_m_full;   /* sum over full-stat calls of M                          */
+    int64_t sum_m2_full;  /* sum over full-stat calls of M*M                        */
+    int64_t m_final;      /* active-set size at exit                                */
+    int64_t m_max;        /* largest active set seen                                */
+    int64_t status;       /* 0 ok; bit0 active set hit capacity; bit1 Cholesky failed;
+                             bit2 stale-index delete path (reference UB) taken      */
+} eben_counters;
+
+/* Gaussian, main effects.  Follows EBEN_orig/src/elasticNetLinearNeMainEff.c:55-242.
+ * X is N x K column-major, Beta is K x 4 column-major (loc1, loc2, beta, var). */
+int eben_gm_fit(const double *X, const double *y, int N, int K, double lambda, double alpha,
+                double *Beta, double *wald, double *intercept, double *residual,
+                eben_counters *cnt);
+
+/* Gaussian, main + pairwise epistasis.  Follows EBEN_orig/src/elasticNetLinearNeFull2.c:57-261.
+ * Beta is K(K+1)/2 x 5 column-major (loc1, loc2, beta, var, used). */
+int eben_gf_fit(const double *X, const double *y, int N, int K, double lambda, double alpha,
+                double *Beta, double *wald, double *intercept, double *residual,
+                eben_counters *cnt);
+
+/* Binomial, main effects.  Follows EBEN_orig/src/ElasticNetBinaryNEmainEff.c:236-389.
+ * Beta is K x 4 column-major; intercept[2] = (mu0, sigma00). */
+int eben_bm_fit(const double *X, const double *y, int N, int K, double lambda, double alpha,
+                double *loglik, double *Beta, double *wald, double *intercept,
+                eben_counters *cnt);
+
+/* Whole CV grid: for each cell c and fold f (1..n_folds) fit on rows fold_id != f and score the
+ * rows fold_id == f exactly as R/TestModel.R:6-39 + R/GetModelError.R:6-59 do.
+ * prior: 0 gaussian (fold SSE), 1 binomial (mean log-lik).  epis: 0/1.
+ * fold_err[c*n_folds + (f-1)].  n_threads <= 0 -> all cores (OpenMP). */
+int eben_cv_grid(const double *basis, int n, int p, const double *y, const int32_t *fold_id,
+                 int n_folds, const double *alpha, const double *lambda, int n_cells,
+                 int prior, int epis, int n_threads, double *fold_err, eben_counters *cnt);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,654 @@
+// gm_fit.h -- one Gaussian main-effect EBEN fit executed by ONE workgroup.
+//
+// What it computes is what EBEN_orig/src/elasticNetLinearNeMainEff.c computes for one
+// (training fold, alpha, lambda): the outer intercept loop (:155-197) around the inner
+// add / re-estimate / delete marginal-likelihood ascent (:248-809).  How it computes it is
+// different and MI355X-first:
+//
+//   * Gram space.  The reference caches BASIS_PHI[l][i] = x_i . Phi_l / scale_i per fit and
+//     rebuilds it by sweeping the N x K design at every add (:1608-1630) and every outer
+//     iteration (:1144-1201).  Phi_l is just the normalised design column of the l-th active
+//     feature, so that row depends only on (fold, feature): it is row used[l] of the fold's
+//     normalised Gram matrix F.G, computed once per fold by gram_kernel and shared by every
+//     (alpha, lambda) cell.  Likewise Phi'Phi (:1874) = G[used,used], Phi't (:1266) =
+//     bt[used], Phi'1 = cs[used].  The fit never sweeps the design; its HBM traffic is Gram
+//     rows (8*K*M bytes per action / full-stat) and a handful of K-vectors.
+//   * One workgroup per fit; every K-, M- and M^2-sized loop is spread over the workgroup;
+//     reductions are fixed trees (blk.h) so results do not depend on timing or GPU count.
+//   * Sigma is updated in place (rank-1 up/down-dates, bordered add, swap-with-last delete)
+//     with a fixed leading dimension instead of the reference's SIGMANEW copy.
+//
+// Reference quirks kept because they change results: Q1 first basis is
+// column 0 and is force-deleted once in outer iteration 1; Q2 the deleted weight is truncated to
+// an int; Q3 gamma[0] is not refreshed by the full-stat pass; Q4 stale roots inside a block
+// update; the stale-slot delete when the forced removal finds column 0 already gone.
+#pragma once
+#include "blk.h"
+#include "types.h"
+#if defined(PAREBEN_HOST_EMUL) && defined(PAREBEN_TRACE)
+#include <stdio.h>
+#define GM_TRACE(...) fprintf(stderr, __VA_ARGS__)
+#else
+#define GM_TRACE(...)
+#endif
+
+enum { ACT_NONE = -10, ACT_REEST = 0, ACT_ADD = 1, ACT_DEL = -1, ACT_TERM = 10 };
+enum { UP_FREE = -1, UP_LOST = -2 };
+
+struct GmScalars {
+    double beta;       // noise precision
+    double b;          // intercept
+    int M;             // active-set size
+    int status;
+    FitCounters *c;    // one copy per workgroup (LDS), updated by thread 0 only
+};
+#define CNT(stmt) do { if (B.tid == 0) { FitCounters &c = *S.c; stmt; } } while (0)
+
+// S_out/Q_out from S_in/Q_in, MainEff.c:1320-1338 and :664-671
+DEV void gm_refresh_out(const Blk &B, const GmWork &W, int K)
+{
+    PAR(i, K) {
+        double s = W.Sin[i], q = W.Qin[i];
+        int l = W.upos[i];
+        if (l >= 0) {
+            double a = W.A[l];
+            W.Sout[i] = a * s / (a - s);
+            W.Qout[i] = a * q / (a - s);
+        } else {
+            W.Sout[i] = s;
+            W.Qout[i] = q;
+        }
+    }
+    blk_sync(B);
+}
+
+// S_in[i] = beta - beta^2 b_i' Sigma b_i,  Q_in[i] = beta (bt_i - b_i' mu)  for every feature,
+// b_i = G[used, i].  MainEff.c:1291-1319.  This is the K*M^2 contraction that dominates the
+// run time; lanes run over features (coalesced Gram rows), each wavefront owns
+// 8 rows of Sigma per pass and the Gram tile is staged through LDS once per pass.
+DEV void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W, int K, int M,
+                              double beta, double *tile, double *xred)
+{
+    const int ld = W.ld;
+#ifdef PAREBEN_HOST_EMUL
+    (void)tile; (void)xred;
+    for (int i = 0; i < K; i++) {
+        double quad = 0, bm = 0;
+        for (int j = 0; j < M; j++) {
+            double a = 0;
+            for (int p = 0; p < M; p++) a += F.G[(size_t)W.used[p] * K + i] * W.Sig[(size_t)j * ld + p];
+            double bj = F.G[(size_t)W.used[j] * K + i];
+            quad += a * bj;
+            bm += bj * W.mu[j];
+        }
+        W.Sin[i] = beta - beta * quad * beta;
+        W.Qin[i] = beta * (W.bt[i] - bm);
+    }
+#else
+    const int NW = B.nwave;
+    for (int i0 = 0; i0 < K; i0 += 64) {
+        const int i = i0 + B.lane;
+        const int ic = i < K ? i : K - 1;
+        double quad = 0, bm = 0;
+        for (int j0 = 0; j0 < M; j0 += 8 * NW) {
+            const int jb = j0 + B.wave * 8;
+            double acc[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) acc[r] = 0;
+            for (int p0 = 0; p0 < M; p0 += 64) {
+                const int pc = (M - p0) < 64 ? (M - p0) : 64;
+                __syncthreads();
+                for (int p = B.wave; p < pc; p += NW)
+                    tile[p * 64 + B.lane] = F.G[(size_t)W.used[p0 + p] * K + ic];
+                __syncthreads();
+                if (jb < M) {
+                    const double *srow = W.Sig + (size_t)jb * ld + p0;
+                    if (jb + 8 <= M) {
+                        for (int p = 0; p < pc; p++) {
+                            const double bv = tile[p * 64 + B.lane];
+#pragma unroll
+                            for (int r = 0; r < 8; r++) acc[r] += srow[(size_t)r * ld + p] * bv;
+                        }
+                    } else {
+                        for (int p = 0; p < pc; p++) {
+                            const double bv = tile[p * 64 + B.lane];
+#pragma unroll
+                            for (int r = 0; r < 8; r++)
+                                if (jb + r < M) acc[r] += srow[(size_t)r * ld + p] * bv;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int j = jb + r;
+                if (j < M) {
+                    const double bj = F.G[(size_t)W.used[j] * K + ic];
+                    quad += acc[r] * bj;
+                    bm += bj * W.mu[j];
+                }
+            }
+        }
+        __syncthreads();
+        xred[B.wave * 64 + B.lane] = quad;
+        xred[(NW + B.wave) * 64 + B.lane] = bm;
+        __syncthreads();
+        if (B.wave == 0 && i < K) {
+            double q = 0, m = 0;
+            for (int w = 0; w < NW; w++) { q += xred[w * 64 + B.lane]; m += xred[(NW + w) * 64 + B.lane]; }
+            W.Sin[i] = beta - beta * q * beta;
+            W.Qin[i] = beta * (W.bt[i] - m);
+        }
+    }
+#endif
+    blk_sync(B);
+}
+
+// Full statistics, MainEff.c:1209-1341 (Q3: gamma[0] is left alone).
+DEV void gm_fullstat(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScalars &S,
+                     bool very_first, double *tile, double *xred)
+{
+    const int M = S.M, ld = W.ld;
+    const double beta = S.beta;
+    if (very_first) {
+        if (B.tid == 0) {
+            W.H[0] = F.G[0] * beta + W.A[0];
+            W.Sig[0] = 1 / W.H[0];
+        }
+    }
+    PAR(l, M) W.v1[l] = W.bt[W.used[l]];                     // Phi' t
+    blk_sync(B);
+    PAR(i, M) {
+        double a = 0;
+        for (int j = 0; j < M; j++) a += W.v1[j] * W.Sig[(size_t)j * ld + i];
+        W.mu[i] = a * beta;
+        if (i >= 1) W.gam[i] = 1 - W.Sig[(size_t)i * ld + i] * W.A[i];
+    }
+    blk_sync(B);
+    gm_fullstat_features(B, F, W, K, M, beta, tile, xred);
+    gm_refresh_out(B, W, K);
+    CNT(c.n_fullstat++; c.sum_m_full += M; c.sum_m2_full += (int64_t)M * M);
+}
+
+// Per-feature marginal-likelihood change and action, MainEff.c:1372-1582.  Returns the arg-max
+// feature and its value.  Ties: lowest index (the reference's first scan visits the active set
+// first; a tie across the two lists needs bit-equal dML of different action types).
+DEV int gm_delta_ml(const Blk &B, const GmWork &W, int K, int N, int M, double lambda, double alpha,
+                    double residual, double varY, int iter, int i_iter, int *any_del_out, double *best)
+{
+    const double l1 = lambda * alpha, l2 = lambda * (1 - alpha);
+    int prio_add = 0, prio_del = 0;
+    if (M < 10) { prio_add = 1; prio_del = 0; }
+    if (M > 100 || M >= N || residual <= varY * 0.1) { prio_add = 0; prio_del = 1; }
+    int my_add = 0, my_del = 0;
+    PAR(i, K) {
+        const int l = W.upos[i];
+        if (l == UP_LOST) { W.act[i] = ACT_NONE; continue; }   // in neither list: stale dML stays
+        const double so = W.Sout[i], qo = W.Qout[i];
+        double d_ml = 0;
+        int act = ACT_NONE;
+        const double a = so - qo * qo + 2 * l1 + l2;
+        const double bq = (so + l2) * (so + 4 * l1 + l2);
+        const double g = 2 * l1 * (so + l2) * (so + l2);
+        const double disc = bq * bq - 4 * a * g;
+        if (a < 0 && disc > 0) {
+            const double r = (-bq - sqrt(disc)) / (2 * a);
+            const double L = (log(r / (r + so + l2)) + qo * qo / (r + so + l2)) * 0.5 - l1 / r;
+            if (L > 0) {
+                W.aroot[i] = r + l2;
+                if (l >= 0) {
+                    act = ACT_REEST;
+                    const double o = W.A[l] - l2;
+                    d_ml = 0.5 * (log(r * (o + so + l2) / (o * (r + so + l2))) +
+                                  qo * qo * (1 / (r + so + l2) - 1 / (o + so + l2))) -
+                           l1 * (1 / r - 1 / o);
+                } else {
+                    act = ACT_ADD;
+                    d_ml = L;
+                    my_add = 1;
+                }
+            }
+        } else if (l >= 0 && M > 1) {
+            my_del = 1;
+            act = ACT_DEL;
+            const double o = W.A[l] - l2;
+            const double L = (log(o / (o + so + l2)) + qo * qo / (o + so + l2)) * 0.5 - l1 / o;
+            d_ml = -L;
+        }
+        W.act[i] = (signed char)act;
+        W.dml[i] = d_ml;
+    }
+    const int any_add = blk_or(B, my_add);
+    const int any_del = blk_or(B, my_del);
+    *any_del_out = any_del;
+    bool rescanned = false;
+    if ((any_add && prio_add) || (any_del && prio_del)) {
+        PAR(i, K) {
+            const int act = W.act[i];
+            if (act == ACT_REEST) W.dml[i] = 0;
+            else if (act == ACT_DEL) { if (any_add && prio_add && !prio_del) W.dml[i] = 0; }
+            else if (act == ACT_ADD) { if (any_del && prio_del && !prio_add) W.dml[i] = 0; }
+        }
+        rescanned = true;
+    }
+    if ((!any_add && iter == 1 && i_iter < 10) || (!any_add && residual >= varY * 0.95)) {
+        PAR(i, K) if (W.act[i] == ACT_DEL) W.dml[i] = 0;
+        rescanned = true;
+    }
+    blk_sync(B);
+    double v = 0; int idx = 0x7fffffff;
+    PAR(i, K) {
+        if (!rescanned && W.upos[i] == UP_LOST) continue;    // first scan walks the two lists only
+        const double d = W.dml[i];
+        if (d > v) { v = d; idx = i; }
+    }
+    double bv; int bi;
+    blk_argmax(B, v, idx, &bv, &bi);
+    if (!(bv > 0)) { bv = 0; bi = 0; }
+    *best = bv;
+    return bi;
+}
+
+// ordered list of features with dML >= cutoff (ascending index), MainEff.c:463-473
+DEV int gm_collect(const Blk &B, const GmWork &W, int K, double cutoff)
+{
+    int base = 0;
+    for (int i0 = 0; i0 < K; i0 += B.nthr) {
+        const int i = i0 + B.tid;
+        const int f = (i < K && W.dml[i] >= cutoff) ? 1 : 0;
+        int tot;
+        const int off = blk_scan_excl(B, f, &tot);
+        if (f) W.todo[base + off] = i;
+        base += tot;
+    }
+    blk_sync(B);
+    return base;
+}
+
+// a[i] = sum_j G[used[j], i] * vec[j] for all features, fused with the S_in/Q_in update that
+// consumes it.  mode 0: re-estimate (:577-587), 1: add (:1699-1711), 2: delete (:1800-1808).
+DEV void gm_sq_update(const Blk &B, const FoldDev &F, const GmWork &W, int K, int M, const double *vec,
+                      int mode, double beta, double c1, double c2, const double *newrow)
+{
+    PAR(i, K) {
+        double a = 0;
+        for (int j = 0; j < M; j++) a += F.G[(size_t)W.used[j] * K + i] * vec[j];
+        if (mode == 0) {                         // c1 = kappa, c2 = mu_jj
+            const double ba = beta * a;
+            W.Sin[i] = W.Sin[i] + ba * ba * c1;
+            W.Qin[i] = W.Qin[i] + beta * c2 * c1 * a;
+        } else if (mode == 1) {                  // c1 = s_ii, c2 = mu_i
+            const double mc = beta * newrow[i] - beta * a;
+            W.Sin[i] = W.Sin[i] - mc * mc * c1;
+            W.Qin[i] = W.Qin[i] - c2 * mc;
+        } else {                                 // c1 = Sigma_jj, c2 = (int) mu_jj
+            const double ba = beta * a;
+            W.Sin[i] = W.Sin[i] + ba * ba / c1;
+            W.Qin[i] = W.Qin[i] + ba * c2 / c1;
+        }
+    }
+    blk_sync(B);
+}
+
+// re-estimate slot jj, MainEff.c:553-596
+DEV void gm_reestimate(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScalars &S, int jj, double newA)
+{
+    const int M = S.M, ld = W.ld;
+    PAR(i, M) W.v2[i] = W.Sig[(size_t)jj * ld + i];
+    blk_sync(B);
+    const double oldA = W.A[jj];
+    const double dinv = 1.0 / (newA - oldA);
+    const double kappa = 1.0 / (W.v2[jj] + dinv);
+    const double mujj = W.mu[jj];
+    blk_sync(B);
+    if (B.tid == 0) W.A[jj] = newA;
+    PAR(i, M) W.mu[i] += (-mujj * kappa) * W.v2[i];
+    for (int j = B.wave; j < M; j += B.nwave) {
+        const double f = kappa * W.v2[j];
+        for (int i = B.lane; i < M; i += BLK_LANES) W.Sig[(size_t)j * ld + i] -= f * W.v2[i];
+    }
+    gm_sq_update(B, F, W, K, M, W.v2, 0, S.beta, kappa, mujj, nullptr);
+}
+
+// add feature nu, MainEff.c:1585-1723 + :613-627
+DEV void gm_add(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScalars &S, int nu, double newA)
+{
+    const int M = S.M, ld = W.ld;
+    const double beta = S.beta;
+    const double *row = F.G + (size_t)nu * K;                 // x_i . phi_nu / scale_i
+    PAR(l, M) W.v1[l] = beta * row[W.used[l]];                // beta Phi' phi
+    blk_sync(B);
+    PAR(i, M) {
+        double a = 0;
+        for (int j = 0; j < M; j++) a += W.Sig[(size_t)i * ld + j] * W.v1[j];
+        W.v2[i] = a;                                          // Sigma * (beta Phi' phi)
+    }
+    const double sii = 1.0 / (newA + W.Sin[nu]);
+    const double mui = sii * W.Qin[nu];
+    blk_sync(B);
+    PAR(i, M) W.mu[i] += -mui * W.v2[i];
+    for (int j = B.wave; j < M; j += B.nwave) {
+        const double f = sii * W.v2[j];
+        for (int i = B.lane; i < M; i += BLK_LANES) W.Sig[(size_t)j * ld + i] += f * W.v2[i];
+    }
+    PAR(i, M) {
+        const double si = -sii * W.v2[i];
+        W.Sig[(size_t)M * ld + i] = si;
+        W.Sig[(size_t)i * ld + M] = si;
+    }
+    if (B.tid == 0) {
+        W.Sig[(size_t)M * ld + M] = sii;
+        W.A[M] = newA;
+        W.mu[M] = mui;
+        W.used[M] = nu;
+        W.upos[nu] = M;
+    }
+    gm_sq_update(B, F, W, K, M, W.v2, 1, beta, sii, mui, row);
+    GM_TRACE("    add nu=%d newA=%.15g sii=%.15g mui=%.15g tp0=%.15g tmp0=%.15g Sin=%.15g Qin=%.15g mu0=%.15g\n", nu, newA, sii, mui, W.v2[0], W.v1[0], W.Sin[nu], W.Qin[nu], W.mu[0]);
+    S.M = M + 1;
+}
+
+// delete slot jj, MainEff.c:1725-1822 + :640-651.  `nu` is the feature the action named; it
+// differs from used[jj] only on the reference's stale-slot path.
+DEV void gm_delete(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScalars &S, int jj, int nu)
+{
+    const int M = S.M, ld = W.ld, last = M - 1;
+    PAR(i, M) W.v2[i] = W.Sig[(size_t)jj * ld + i];
+    blk_sync(B);
+    const double sjj = W.v2[jj];
+    const int mujj = (int)W.mu[jj];                           // Q2: int truncation
+    const int gone = W.used[jj];
+    gm_sq_update(B, F, W, K, M, W.v2, 2, S.beta, sjj, (double)mujj, nullptr);
+    PAR(i, M) W.mu[i] = W.mu[i] - mujj * W.v2[i] / sjj;
+    for (int j = B.wave; j < M; j += B.nwave) {
+        const double vj = W.v2[j];
+        for (int i = B.lane; i < M; i += BLK_LANES) W.Sig[(size_t)j * ld + i] -= W.v2[i] / sjj * vj;
+    }
+    blk_sync(B);
+    if (jj != last) {                                         // move the last slot into jj
+        PAR(i, M) { W.v3[i] = W.Sig[(size_t)last * ld + i]; W.v4[i] = W.Sig[(size_t)i * ld + last]; }
+        blk_sync(B);
+        PAR(i, last) {
+            if (i != jj) {
+                W.Sig[(size_t)jj * ld + i] = W.v3[i];         // column jj <- column last
+                W.Sig[(size_t)i * ld + jj] = W.v4[i];         // row jj    <- row last
+            }
+        }
+        if (B.tid == 0) {
+            W.Sig[(size_t)jj * ld + jj] = W.v3[last];
+            W.A[jj] = W.A[last];
+            W.mu[jj] = W.mu[last];
+            W.used[jj] = W.used[last];
+            W.upos[W.used[last]] = jj;
+        }
+    }
+    if (B.tid == 0) {
+        if (gone == nu) W.upos[gone] = UP_FREE;
+        else { W.upos[gone] = UP_LOST; }
+    }
+    S.M = last;
+    blk_sync(B);
+}
+
+// Sigma <- H^-1 for the SPD M x M matrix held in Sig (in place, Gauss-Jordan without pivoting:
+// the pivots are the Cholesky pivots squared, so a non-positive pivot means "not SPD").
+// Stands in for dpotrf+dpotri (:1346-1369).  Returns 0 on success.
+DEV int gm_spd_inverse(const Blk &B, const GmWork &W, int M)
+{
+    const int ld = W.ld;
+    for (int k = 0; k < M; k++) {
+        PAR(i, M) { W.v3[i] = W.Sig[(size_t)k * ld + i]; W.v4[i] = W.Sig[(size_t)i * ld + k]; }
+        blk_sync(B);
+        const double d = W.v3[k];
+        if (!(d > 0)) return 1;
+        const double rd = 1.0 / d;
+        for (int j = B.wave; j < M; j += B.nwave) {
+            const double rkj = W.v4[j] * rd;
+            for (int i = B.lane; i < M; i += BLK_LANES) {
+                double a;
+                if (i == k) a = (j == k) ? rd : rkj;
+                else if (j == k) a = -W.v3[i] * rd;
+                else a = W.Sig[(size_t)j * ld + i] - W.v3[i] * rkj;
+                W.Sig[(size_t)j * ld + i] = a;
+            }
+        }
+        blk_sync(B);
+    }
+    return 0;
+}
+
+// H = beta Phi'Phi + diag(A); Sigma = H^-1; mu = beta Sigma Phi't.  MainEff.c:1841-1921
+DEV int gm_final_update(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScalars &S)
+{
+    const int M = S.M, ld = W.ld;
+    const double beta = S.beta;
+    for (int j = B.wave; j < M; j += B.nwave) {
+        const int uj = W.used[j];
+        for (int i = B.lane; i < M; i += BLK_LANES) {
+            const int ui = W.used[i];
+            // Phi_i.Phi_j from the Gram matrix; one triangle so that H is exactly symmetric
+            double h = (i <= j ? F.G[(size_t)ui * K + uj] : F.G[(size_t)uj * K + ui]) * beta;
+            if (i == j) h += W.A[i];
+            W.H[(size_t)j * ld + i] = h;
+            W.Sig[(size_t)j * ld + i] = h;
+        }
+    }
+    PAR(l, M) W.v1[l] = W.bt[W.used[l]];
+    blk_sync(B);
+    if (gm_spd_inverse(B, W, M)) return 1;
+    PAR(i, M) {
+        double a = 0;
+        for (int j = 0; j < M; j++) a += W.v1[j] * W.Sig[(size_t)j * ld + i];
+        W.mu[i] = a * beta;
+    }
+    blk_sync(B);
+    return 0;
+}
+
+// One call of the inner routine (MainEff.c:248-809) for outer iteration `iter`.  On return
+// *cs = sum_i Csum_i and *csy = Csum.y with Csum the column sums of
+// C^-1 = beta I - beta^2 Phi Sigma Phi' (:741-781, :172-187), formed in O(N M + M^2).
+DEV int gm_inner(const Blk &B, const FoldDev &F, const GmWork &W, int K, double lambda, double alpha,
+                 GmScalars &S, int iter, double residual, double varY, double *cs, double *csy,
+                 double *tile, double *xred)
+{
+    const int N = F.N, ld = W.ld;
+    const bool first = iter <= 1;
+    if (first) {                                              // :1003-1090, Q1
+        S.M = 1;
+        S.beta = 1 / (varY * 0.01 + 1e-10);
+        PAR(i, K) W.upos[i] = UP_FREE;
+        blk_sync(B);
+        if (B.tid == 0) {
+            W.used[0] = 0;
+            W.upos[0] = 0;
+            const double p = F.G[0] * S.beta;
+            const double q = (F.bt0[0] - S.b * F.cs[0]) * S.beta;
+            double a0 = p * p / (q * q - p);
+            if (a0 < 0) a0 = 1e2;
+            if (a0 > 1e2) a0 = 1e2;
+            W.A[0] = a0;
+        }
+    } else {
+        PAR(i, K) if (W.upos[i] == UP_LOST) W.upos[i] = UP_FREE;   // :1092-1107 rebuilds the list
+    }
+    PAR(i, W.cap + 1) W.gam[i] = 0;                          // calloc per call, :344
+    PAR(i, K) W.bt[i] = F.bt0[i] - S.b * F.cs[i];            // x_i.(y - b)/scale_i, :1171-1177
+    blk_sync(B);
+    const int initial = W.used[0];
+    int ini_removed = first ? 0 : 1;
+    int i_iter = 0;
+    gm_fullstat(B, F, W, K, S, iter == 1, tile, xred);
+
+    int sel = ACT_NONE, jj = -1, n_todo = 0, last_it = 0;
+    const int it_max = iter == 1 ? 10 : 100;
+    while (!last_it) {
+        i_iter++;
+        CNT(c.n_inner++);
+        double best; int any_del;
+        int nu = gm_delta_ml(B, W, K, N, S.M, lambda, alpha, residual, varY, iter, i_iter, &any_del, &best);
+        int worthwhile;
+        if (sel == ACT_TERM && !ini_removed && S.M > 1) nu = -1;
+        if (nu == -1 && ini_removed) {
+            worthwhile = 0; sel = ACT_TERM;
+        } else if (nu == -1 && !ini_removed && S.M > 1) {     // forced removal, :437-446
+            worthwhile = 1;
+            nu = initial;
+            if (B.tid == 0) { W.act[nu] = ACT_DEL; W.todo[0] = initial; }
+            blk_sync(B);
+            n_todo = 1;
+            ini_removed = 1;
+            sel = ACT_DEL;
+        } else {
+            worthwhile = 1;
+            const int act_nu = W.act[nu];
+            double cutoff = best * (act_nu == ACT_ADD ? 0.9 : 1.0);
+            if (cutoff < 0.001) cutoff = 0.001;
+            n_todo = gm_collect(B, W, K, cutoff);
+            if (act_nu == ACT_DEL && n_todo > 1) n_todo = 1;
+            if (n_todo == 0) worthwhile = 0;
+        }
+        if (!worthwhile) sel = ACT_TERM;
+        if (worthwhile) {
+            for (int u = 0; u < n_todo; u++) {
+                nu = W.todo[u];
+                sel = W.act[nu];
+                const double newA = W.aroot[nu];
+                if (sel == ACT_REEST || sel == ACT_DEL) {
+                    const int l = W.upos[nu];
+                    if (l >= 0) jj = l;
+                    else {                                    // stale slot (reference UB path)
+                        S.status |= ST_STALE;
+                        if (jj < 0 || jj >= S.M) { S.status |= ST_ABORT; return 1; }
+                    }
+                }
+                if (sel == ACT_REEST && fabs(log(newA) - log(W.A[jj])) <= 1e-3 && any_del == 0)
+                    sel = ACT_TERM;
+                blk_sync(B);
+                bool upd = false;
+                if (sel == ACT_REEST) {
+                    CNT(c.n_reest++; c.sum_m_action += S.M);
+                    gm_reestimate(B, F, W, K, S, jj, newA);
+                    upd = true;
+                } else if (sel == ACT_ADD) {
+                    if (S.M + 1 > W.cap) { S.status |= ST_OVERFLOW | ST_ABORT; return 1; }
+                    CNT(c.n_add++; c.sum_m_action += S.M);
+                    gm_add(B, F, W, K, S, nu, newA);
+                    upd = true;
+                } else if (sel == ACT_DEL) {
+                    CNT(c.n_del++; c.sum_m_action += S.M);
+                    gm_delete(B, F, W, K, S, jj, nu);
+                    upd = true;
+                }
+                if (upd) {
+                    blk_sync(B);
+                    gm_refresh_out(B, W, K);
+                    PAR(i, S.M) W.gam[i] = 1 - W.A[i] * W.Sig[(size_t)i * ld + i];
+                    blk_sync(B);
+                    CNT(if (S.M > c.m_max) c.m_max = S.M);
+                }
+            }
+        }
+        if (sel == ACT_TERM || i_iter <= 10 || i_iter % 5 == 0 || n_todo >= 2) {   // :685-729
+            const int M = S.M;
+            double ee_part = 0;
+            PAR(h, N) {
+                double pm = 0;
+                for (int j = 0; j < M; j++) {
+                    const int uj = W.used[j];
+                    pm += W.mu[j] * (F.X[(size_t)uj * N + h] * F.rscale[uj]);
+                }
+                const double e = (F.y[h] - S.b) - pm;
+                ee_part += e * e;
+            }
+            const double ee = blk_sum(B, ee_part);
+            double g_part = 0;
+            PAR(i, M) g_part += W.gam[i];
+            const double gsum = blk_sum(B, g_part);
+            const double beta_old = S.beta;
+            double nb = (N - gsum) / ee;
+            if (nb > 1e6 / varY) nb = 1e6 / varY;
+            S.beta = nb;
+            const double dlb = log(nb) - log(beta_old);
+            if (fabs(dlb) > 1e-6) {
+                if (gm_final_update(B, F, W, K, S)) { S.status |= ST_CHOLESKY | ST_ABORT; return 1; }
+                if (sel != ACT_TERM) gm_fullstat(B, F, W, K, S, false, tile, xred);
+            }
+        }
+        GM_TRACE("  it %d.%d M=%d sel=%d ntodo=%d beta=%.15g mu0=%.15g A0=%.15g gam0=%.15g\n", iter, i_iter, S.M, sel, n_todo, S.beta, W.mu[0], W.A[0], W.gam[0]);
+        if (sel == ACT_TERM && ini_removed) last_it = 1;
+        if ((i_iter == it_max && S.M == 1) || i_iter > it_max) last_it = 1;
+        if (i_iter == it_max) sel = ACT_TERM;
+    }
+    {   // column sums of C^-1
+        const int M = S.M;
+        PAR(l, M) W.v1[l] = F.cs[W.used[l]];                 // Phi' 1
+        blk_sync(B);
+        PAR(i, M) {
+            double a = 0;
+            for (int j = 0; j < M; j++) a += W.v1[j] * W.Sig[(size_t)j * ld + i];
+            W.v2[i] = a;
+        }
+        blk_sync(B);
+        const double beta = S.beta, b2 = beta * beta;
+        double a_part = 0, b_part = 0;
+        PAR(h, N) {
+            double v = 0;
+            for (int j = 0; j < M; j++) {
+                const int uj = W.used[j];
+                v += W.v2[j] * (F.X[(size_t)uj * N + h] * F.rscale[uj]);
+            }
+            const double c = beta - b2 * v;
+            a_part += c;
+            b_part += c * F.y[h];
+        }
+        *cs = blk_sum(B, a_part);
+        *csy = blk_sum(B, b_part);
+    }
+    return 0;
+}
+
+// The whole fit: MainEff.c:55-242.  On return S.b = intercept, S.beta = noise precision,
+// W.used/W.mu/W.Sig hold the model (mu in normalised-column units).
+DEV void gm_fit(const Blk &B, const FoldDev &F, const GmWork &W, int K, double lambda, double alpha,
+                GmScalars &S, double *tile, double *xred)
+{
+    S.b = F.ymean;
+    S.status = 0;
+    S.M = 1;
+    CNT(c = FitCounters{});
+    const double varT = F.varY;
+    double residvar = 1e10, err = 1000, vk = 1e-30, vk0;
+    int iter = 0;
+    while (iter < 100 && err > 1e-8 && residvar >= varT * 0.01) {
+        iter++;
+        vk0 = vk;
+        double cs, csy;
+        if (gm_inner(B, F, W, K, lambda, alpha, S, iter, residvar, varT, &cs, &csy, tile, xred)) break;
+        S.b = csy / (cs + 1e-10);
+        double a_part = 0;
+        PAR(i, S.M) a_part += W.A[i];
+        vk = blk_sum(B, a_part);
+        err = fabs(vk - vk0) / S.M;
+        residvar = 1 / (S.beta + 1e-10);
+    }
+    CNT(c.n_outer = iter; c.m_final = S.M; if (S.M > c.m_max) c.m_max = S.M; c.status = S.status);
+    blk_sync(B);
+}
+
+// fold score, R/GetModelError.R:7-32: SSE of the held-out rows under the fitted model
+DEV double gm_fold_sse(const Blk &B, const FoldDev &F, const GmWork &W, const GmScalars &S)
+{
+    const int nte = F.nte, M = S.M;
+    double part = 0;
+    PAR(h, nte) {
+        double pred = 0;
+        for (int j = 0; j < M; j++) {
+            const int uj = W.used[j];
+            pred += F.Xte[(size_t)uj * nte + h] * (W.mu[j] / F.scale[uj]);
+        }
+        const double r = F.yte[h] - (S.b + pred);
+        part += r * r;
+    }
+    return blk_sum(B, part);
+}

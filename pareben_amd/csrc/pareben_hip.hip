@@ -1,0 +1,626 @@
+// pareben_hip.hip -- kernels and C ABI of libpareben_hip.so (gfx950 only).
+//
+// Data flow of one pareben_ctx_run():
+//   BASIS, Target, fold ids (resident in HBM since ctx_create)
+//     -> split_kernel      per fold: training / held-out rows compacted, column-major
+//     -> colstats_kernel   per fold, per column: |x|, 1/|x|, x.y/|x|, x.1/|x|
+//     -> ystats_kernel     per fold: mean and unbiased variance of the training target
+//     -> gram_kernel       per fold: normalised Gram matrix G (K x K), LDS-tiled FP64
+//     -> gm_cv_kernel      persistent workgroups pull (cell, fold) units, heaviest first, from
+//                          an atomic queue; one workgroup = one fit + its held-out score
+//     -> fold_err / status / counters copied back
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <vector>
+#include <algorithm>
+#include <numeric>
+#include <string>
+
+#include "../../include/pareben_hip.h"
+#include "types.h"
+#include "blk.h"
+#include "gm_fit.h"
+
+// ------------------------------------------------------------------------------------------
+// error plumbing
+static thread_local std::string g_err;
+static int fail(int code, const char *what, hipError_t e = hipSuccess)
+{
+    char buf[512];
+    if (e != hipSuccess) snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    else snprintf(buf, sizeof buf, "%s", what);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(PAREBEN_EHIP, #x, e_); } while (0)
+
+extern "C" const char *pareben_version(void) { return "pareben-hip 0.1 (gfx950)"; }
+extern "C" const char *pareben_last_error(void) { return g_err.c_str(); }
+extern "C" int pareben_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ------------------------------------------------------------------------------------------
+// preparation kernels
+
+// rows[] lists the source rows of this fold's training (or held-out) set; one workgroup per column
+__global__ void split_kernel(const double *__restrict__ basis, int n, const int *__restrict__ rows,
+                             int nr, double *__restrict__ out)
+{
+    const int j = blockIdx.x;
+    const double *src = basis + (size_t)j * n;
+    double *dst = out + (size_t)j * nr;
+    for (int r = threadIdx.x; r < nr; r += blockDim.x) dst[r] = src[rows[r]];
+}
+
+__global__ void gather_kernel(const double *__restrict__ y, const int *__restrict__ rows, int nr,
+                              double *__restrict__ out)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < nr) out[r] = y[rows[r]];
+}
+
+__device__ __forceinline__ double block_sum_256(double v, double *sh)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); w++) s += sh[w];
+    return s;
+}
+
+// per column: scale = |x| (1 when 0), rscale, bt0 = x.y/scale, cs = x.1/scale
+// (elasticNetLinearNeMainEff.c:87-99 and the y- and 1-parts of :1171-1177)
+__global__ void colstats_kernel(const double *__restrict__ X, const double *__restrict__ y, int N,
+                                double *__restrict__ scale, double *__restrict__ rscale,
+                                double *__restrict__ bt0, double *__restrict__ cs)
+{
+    __shared__ double sh[16];
+    const int j = blockIdx.x;
+    const double *x = X + (size_t)j * N;
+    double q = 0, xy = 0, x1 = 0;
+    for (int h = threadIdx.x; h < N; h += blockDim.x) {
+        const double v = x[h];
+        q += v * v; xy += v * y[h]; x1 += v;
+    }
+    q = block_sum_256(q, sh);
+    xy = block_sum_256(xy, sh);
+    x1 = block_sum_256(x1, sh);
+    if (threadIdx.x == 0) {
+        if (q == 0) q = 1;
+        const double s = sqrt(q);
+        scale[j] = s; rscale[j] = 1 / s; bt0[j] = xy / s; cs[j] = x1 / s;
+    }
+}
+
+// out[0] = sum(y)/N, out[1] = unbiased variance (:145-152, :1826-1838)
+__global__ void ystats_kernel(const double *__restrict__ y, int N, double *__restrict__ out)
+{
+    __shared__ double sh[16];
+    double s = 0;
+    for (int h = threadIdx.x; h < N; h += blockDim.x) s += y[h];
+    s = block_sum_256(s, sh);
+    const double m = s / N;
+    double v = 0;
+    for (int h = threadIdx.x; h < N; h += blockDim.x) { const double d = y[h] - m; v += d * d; }
+    v = block_sum_256(v, sh);
+    if (threadIdx.x == 0) { out[0] = m; out[1] = v / (N - 1); }
+}
+
+// G[u*K + i] = ( sum_h X[h,i] * (X[h,u] * rscale[u]) ) / scale[i].  64 x 64 output tile per
+// 256-thread workgroup, 4 x 4 register tile per thread, 16-deep K-slabs staged through LDS.
+#define GT 64
+#define GK 16
+__global__ __launch_bounds__(256) void gram_kernel(const double *__restrict__ X, int N, int K,
+                                                   const double *__restrict__ scale,
+                                                   const double *__restrict__ rscale,
+                                                   double *__restrict__ G)
+{
+    __shared__ double sI[GK][GT + 1];
+    __shared__ double sU[GK][GT + 1];
+    const int i0 = blockIdx.x * GT, u0 = blockIdx.y * GT;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;    // tx -> i, ty -> u
+    double acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = 0;
+    for (int h0 = 0; h0 < N; h0 += GK) {
+        // 64 columns x 16 rows per operand = 1024 elements, 4 per thread; consecutive threads
+        // read consecutive h of one column (columns are contiguous in h)
+        for (int e = threadIdx.x; e < GT * GK; e += 256) {
+            const int c = e / GK, h = e % GK;
+            const int hh = h0 + h;
+            const int ci = i0 + c, cu = u0 + c;
+            sI[h][c] = (hh < N && ci < K) ? X[(size_t)ci * N + hh] : 0.0;
+            sU[h][c] = (hh < N && cu < K) ? X[(size_t)cu * N + hh] * rscale[cu] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < GK; h++) {
+            double vi[4], vu[4];
+#pragma unroll
+            for (int a = 0; a < 4; a++) { vi[a] = sI[h][tx + 16 * a]; vu[a] = sU[h][ty + 16 * a]; }
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) acc[a][b] += vu[a] * vi[b];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        const int u = u0 + ty + 16 * a;
+        if (u >= K) continue;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int i = i0 + tx + 16 * b;
+            if (i < K) G[(size_t)u * K + i] = acc[a][b] / scale[i];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// workspace carving
+
+struct WsLayout { size_t bytes; int cap, ld; size_t offK, offSig, offM; };
+
+__host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static WsLayout ws_layout(int K, int cap)
+{
+    WsLayout L;
+    L.cap = cap; L.ld = cap;
+    size_t o = 0;
+    L.offK = o;   o += align_up((size_t)K * (7 * sizeof(double) + 2 * sizeof(int) + 1), 256);
+    L.offSig = o; o += align_up((size_t)2 * cap * cap * sizeof(double), 256);
+    L.offM = o;   o += align_up((size_t)(cap + 1) * (7 * sizeof(double) + sizeof(int)), 256);
+    L.bytes = align_up(o, 4096);
+    return L;
+}
+
+__device__ inline GmWork ws_carve(char *base, int K, int cap, size_t offK, size_t offSig, size_t offM)
+{
+    GmWork W;
+    double *d = (double *)(base + offK);
+    W.Sin = d; d += K; W.Qin = d; d += K; W.Sout = d; d += K; W.Qout = d; d += K;
+    W.dml = d; d += K; W.aroot = d; d += K; W.bt = d; d += K;
+    int *ip = (int *)d;
+    W.upos = ip; ip += K; W.todo = ip; ip += K;
+    W.act = (signed char *)ip;
+    d = (double *)(base + offSig);
+    W.Sig = d; d += (size_t)cap * cap; W.H = d;
+    d = (double *)(base + offM);
+    const int c1 = cap + 1;
+    W.A = d; d += c1; W.mu = d; d += c1; W.gam = d; d += c1;
+    W.v1 = d; d += c1; W.v2 = d; d += c1; W.v3 = d; d += c1; W.v4 = d; d += c1;
+    W.used = (int *)d;
+    W.e = nullptr;
+    W.cap = cap; W.ld = cap;
+    return W;
+}
+
+// ------------------------------------------------------------------------------------------
+// fit kernels
+
+#define FIT_THREADS 1024
+
+struct CvParams {
+    const FoldDev *folds;
+    const double *alpha, *lambda;     // per cell
+    const int *order;                 // unit ids (cell * n_folds + fold), heaviest first
+    int *queue;                       // head of the work queue
+    double *fold_err;
+    int *status;
+    long long *counters;              // may be null
+    char *ws;
+    size_t ws_stride, offK, offSig, offM;
+    int K, cap, n_folds, n_units;
+};
+
+__device__ inline Blk make_blk(double *red, int *ired)
+{
+    Blk B;
+    B.tid = threadIdx.x; B.nthr = blockDim.x;
+    B.lane = threadIdx.x & 63;
+    B.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    B.nwave = blockDim.x >> 6;
+    B.red = red; B.ired = ired;
+    return B;
+}
+
+__device__ inline void store_counters(long long *dst, const FitCounters &c)
+{
+    dst[0] = c.n_outer; dst[1] = c.n_inner; dst[2] = c.n_add; dst[3] = c.n_del; dst[4] = c.n_reest;
+    dst[5] = c.n_fullstat; dst[6] = c.sum_m_action; dst[7] = c.sum_m_full; dst[8] = c.sum_m2_full;
+    dst[9] = c.m_final; dst[10] = c.m_max; dst[11] = c.status;
+}
+
+__global__ __launch_bounds__(FIT_THREADS) void gm_cv_kernel(CvParams P)
+{
+    __shared__ double tile[64 * 64];
+    __shared__ double xred[2 * BLK_MAX_WAVES * 64];
+    __shared__ double red[2 * BLK_MAX_WAVES];
+    __shared__ int ired[2 * BLK_MAX_WAVES];
+    __shared__ int s_unit;
+    __shared__ FitCounters s_cnt;
+    const Blk B = make_blk(red, ired);
+    const GmWork W = ws_carve(P.ws + (size_t)blockIdx.x * P.ws_stride, P.K, P.cap, P.offK, P.offSig, P.offM);
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_unit = atomicAdd(P.queue, 1);
+        __syncthreads();
+        const int q = s_unit;
+        if (q >= P.n_units) break;                 // every wave of every workgroup reaches this
+        const int unit = P.order[q];
+        const int cell = unit / P.n_folds, f = unit % P.n_folds;
+        const FoldDev F = P.folds[f];
+        GmScalars S;
+        S.c = &s_cnt;
+        gm_fit(B, F, W, P.K, P.lambda[cell], P.alpha[cell], S, tile, xred);
+        const double sse = gm_fold_sse(B, F, W, S);
+        if (threadIdx.x == 0) {
+            P.fold_err[unit] = sse;
+            P.status[unit] = S.status;
+            if (P.counters) store_counters(P.counters + (size_t)unit * PAREBEN_NCOUNTERS, s_cnt);
+        }
+    }
+}
+
+struct FitParams {
+    FoldDev F;
+    double lambda, alpha;
+    double *Beta;        // K x 4
+    double *scalars;     // wald, intercept, residual
+    int *status;
+    long long *counters;
+    char *ws;
+    size_t offK, offSig, offM;
+    int K, cap;
+};
+
+// single fit with the reference's .C outputs (elasticNetLinearNeMainEff.c:199-227)
+__global__ __launch_bounds__(FIT_THREADS) void gm_fit_kernel(FitParams P)
+{
+    __shared__ double tile[64 * 64];
+    __shared__ double xred[2 * BLK_MAX_WAVES * 64];
+    __shared__ double red[2 * BLK_MAX_WAVES];
+    __shared__ int ired[2 * BLK_MAX_WAVES];
+    __shared__ FitCounters s_cnt;
+    const Blk B = make_blk(red, ired);
+    const GmWork W = ws_carve(P.ws, P.K, P.cap, P.offK, P.offSig, P.offM);
+    const int K = P.K;
+    PAR(i, K) { P.Beta[i] = i + 1; P.Beta[K + i] = i + 1; P.Beta[2 * (size_t)K + i] = 0; P.Beta[3 * (size_t)K + i] = 0; }
+    GmScalars S;
+    S.c = &s_cnt;
+    gm_fit(B, P.F, W, K, P.lambda, P.alpha, S, tile, xred);
+    const int M = S.M, ld = W.ld;
+    PAR(i, M) {
+        const int f = W.used[i];
+        const double sc = P.F.scale[f];
+        P.Beta[2 * (size_t)K + f] = W.mu[i] / sc;
+        P.Beta[3 * (size_t)K + f] = W.Sig[(size_t)i * ld + i] / (sc * sc);
+    }
+    // Wald score mu' H mu with the H of the last final update (:199-215)
+    double part = 0;
+    PAR(i, M) {
+        double a = 0;
+        for (int j = 0; j < M; j++) a += W.mu[j] * W.H[(size_t)i * ld + j];
+        part += a * W.mu[i];
+    }
+    const double wald = blk_sum(B, part);
+    if (threadIdx.x == 0) {
+        P.scalars[0] = wald;
+        P.scalars[1] = S.b;
+        P.scalars[2] = 1 / (S.beta + 1e-10);
+        P.status[0] = S.status;
+        if (P.counters) store_counters(P.counters, s_cnt);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+
+struct FoldHost {
+    int N = 0, nte = 0;
+    int *d_tr = nullptr, *d_te = nullptr;
+    double *X = nullptr, *y = nullptr, *Xte = nullptr, *yte = nullptr;
+    double *scale = nullptr, *rscale = nullptr, *bt0 = nullptr, *cs = nullptr, *G = nullptr;
+    double *ystat = nullptr;
+};
+
+struct pareben_ctx {
+    int device = 0, n = 0, p = 0, n_folds = 0, prior = 0, epis = 0, cap = 0;
+    double *d_basis = nullptr, *d_y = nullptr;
+    std::vector<FoldHost> folds;
+    FoldDev *d_folds = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    char *d_ws = nullptr; size_t ws_bytes = 0; int ws_blocks = 0;
+    WsLayout L{};
+    double last_ms[3] = {0, 0, 0};
+    int64_t launch_info[4] = {0, 0, 0, 0};
+    int n_cu = 0;
+};
+
+static int default_cap(int K, int max_active)
+{
+    long cap = (long)(1e7 / K);
+    if (cap > K) cap = K;
+    if (max_active > 0) { if (cap > max_active) cap = max_active; }
+    else if (cap > 2048) cap = 2048;
+    if (cap < 2) cap = 2;
+    return (int)cap;
+}
+
+template <class T> static hipError_t dmalloc(T **p, size_t count)
+{
+    return hipMalloc((void **)p, count ? count * sizeof(T) : sizeof(T));
+}
+
+extern "C" int pareben_ctx_destroy(pareben_ctx *c)
+{
+    if (!c) return PAREBEN_OK;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (auto &f : c->folds) {
+        hipFree(f.d_tr); hipFree(f.d_te); hipFree(f.X); hipFree(f.y); hipFree(f.Xte); hipFree(f.yte);
+        hipFree(f.scale); hipFree(f.rscale); hipFree(f.bt0); hipFree(f.cs); hipFree(f.G); hipFree(f.ystat);
+    }
+    hipFree(c->d_basis); hipFree(c->d_y); hipFree(c->d_folds); hipFree(c->d_ws);
+    for (auto &e : c->ev) if (e) hipEventDestroy(e);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return PAREBEN_OK;
+}
+
+// rows_tr[f] / rows_te[f]: source rows of fold f's training / held-out set
+static int ctx_create_impl(pareben_ctx **out, int device, const double *basis, int n, int p,
+                           const double *target, const std::vector<std::vector<int>> &rows_tr,
+                           const std::vector<std::vector<int>> &rows_te, int prior, int epis, int max_active)
+{
+    const int n_folds = (int)rows_tr.size();
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(PAREBEN_EINVAL, "no such device");
+    HIPCHK(hipSetDevice(device));
+    pareben_ctx *c = new pareben_ctx();
+    c->device = device; c->n = n; c->p = p; c->n_folds = n_folds; c->prior = prior; c->epis = epis;
+    c->cap = default_cap(p, max_active);
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    c->n_cu = prop.multiProcessorCount;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { pareben_ctx_destroy(c); return fail(e_ == hipErrorOutOfMemory ? PAREBEN_ENOMEM : PAREBEN_EHIP, #x, e_); } } while (0)
+    CK(hipStreamCreate(&c->stream));
+    for (auto &e : c->ev) CK(hipEventCreate(&e));
+    CK(dmalloc(&c->d_basis, (size_t)n * p));
+    CK(dmalloc(&c->d_y, (size_t)n));
+    CK(hipMemcpy(c->d_basis, basis, sizeof(double) * (size_t)n * p, hipMemcpyHostToDevice));
+    CK(hipMemcpy(c->d_y, target, sizeof(double) * n, hipMemcpyHostToDevice));
+    c->folds.resize(n_folds);
+    std::vector<FoldDev> fd(n_folds);
+    for (int f = 0; f < n_folds; f++) {
+        FoldHost &H = c->folds[f];
+        const std::vector<int> &tr = rows_tr[f], &te = rows_te[f];
+        H.N = (int)tr.size(); H.nte = (int)te.size();
+        if (H.N < 2) { pareben_ctx_destroy(c); return fail(PAREBEN_EINVAL, "a fold leaves fewer than 2 training rows"); }
+        CK(dmalloc(&H.d_tr, tr.size())); CK(dmalloc(&H.d_te, te.size()));
+        CK(hipMemcpy(H.d_tr, tr.data(), sizeof(int) * tr.size(), hipMemcpyHostToDevice));
+        if (!te.empty()) CK(hipMemcpy(H.d_te, te.data(), sizeof(int) * te.size(), hipMemcpyHostToDevice));
+        CK(dmalloc(&H.X, (size_t)H.N * p)); CK(dmalloc(&H.y, (size_t)H.N));
+        CK(dmalloc(&H.Xte, (size_t)H.nte * p)); CK(dmalloc(&H.yte, (size_t)H.nte));
+        CK(dmalloc(&H.scale, (size_t)p)); CK(dmalloc(&H.rscale, (size_t)p));
+        CK(dmalloc(&H.bt0, (size_t)p)); CK(dmalloc(&H.cs, (size_t)p));
+        CK(dmalloc(&H.G, (size_t)p * p));
+        CK(dmalloc(&H.ystat, (size_t)2));
+        FoldDev &D = fd[f];
+        D.X = H.X; D.y = H.y; D.Xte = H.Xte; D.yte = H.yte; D.scale = H.scale; D.rscale = H.rscale;
+        D.bt0 = H.bt0; D.cs = H.cs; D.G = H.G; D.ymean = 0; D.varY = 0; D.N = H.N; D.nte = H.nte;
+    }
+    CK(dmalloc(&c->d_folds, (size_t)n_folds));
+    CK(hipMemcpy(c->d_folds, fd.data(), sizeof(FoldDev) * n_folds, hipMemcpyHostToDevice));
+#undef CK
+    *out = c;
+    return PAREBEN_OK;
+}
+
+extern "C" int pareben_ctx_create(pareben_ctx **out, int device, const double *basis, int n, int p,
+                                  const double *target, const int32_t *fold_id, int n_folds,
+                                  int prior, int epis, int max_active)
+{
+    if (!out || !basis || !target || !fold_id || n < 2 || p < 1 || n_folds < 1) return fail(PAREBEN_EINVAL, "bad argument");
+    if (prior != PAREBEN_PRIOR_GAUSSIAN || epis != 0)
+        return fail(PAREBEN_EUNSUPPORTED, "only prior=gaussian, epis=0 is built in this version");
+    for (int i = 0; i < n; i++) if (fold_id[i] < 1 || fold_id[i] > n_folds) return fail(PAREBEN_EINVAL, "fold_id out of 1..n_folds");
+    std::vector<std::vector<int>> tr(n_folds), te(n_folds);
+    for (int f = 0; f < n_folds; f++)
+        for (int i = 0; i < n; i++) (fold_id[i] == f + 1 ? te[f] : tr[f]).push_back(i);
+    return ctx_create_impl(out, device, basis, n, p, target, tr, te, prior, epis, max_active);
+}
+
+// launch the per-fold preparation on the context's stream and patch ymean/varY into d_folds
+static int prepare_folds(pareben_ctx *c)
+{
+    const int p = c->p, n = c->n;
+    for (int f = 0; f < c->n_folds; f++) {
+        FoldHost &H = c->folds[f];
+        hipLaunchKernelGGL(split_kernel, dim3(p), dim3(256), 0, c->stream, c->d_basis, n, H.d_tr, H.N, H.X);
+        if (H.nte) hipLaunchKernelGGL(split_kernel, dim3(p), dim3(256), 0, c->stream, c->d_basis, n, H.d_te, H.nte, H.Xte);
+        hipLaunchKernelGGL(gather_kernel, dim3((H.N + 255) / 256), dim3(256), 0, c->stream, c->d_y, H.d_tr, H.N, H.y);
+        if (H.nte) hipLaunchKernelGGL(gather_kernel, dim3((H.nte + 255) / 256), dim3(256), 0, c->stream, c->d_y, H.d_te, H.nte, H.yte);
+        hipLaunchKernelGGL(colstats_kernel, dim3(p), dim3(256), 0, c->stream, H.X, H.y, H.N, H.scale, H.rscale, H.bt0, H.cs);
+        hipLaunchKernelGGL(ystats_kernel, dim3(1), dim3(256), 0, c->stream, H.y, H.N, H.ystat);
+        dim3 gg((p + GT - 1) / GT, (p + GT - 1) / GT);
+        hipLaunchKernelGGL(gram_kernel, gg, dim3(256), 0, c->stream, H.X, H.N, p, H.scale, H.rscale, H.G);
+        // ymean / varY live inside the FoldDev record: copy the two doubles device-to-device
+        HIPCHK(hipMemcpyAsync((char *)(c->d_folds + f) + offsetof(FoldDev, ymean), H.ystat, 2 * sizeof(double),
+                              hipMemcpyDeviceToDevice, c->stream));
+    }
+    HIPCHK(hipGetLastError());
+    return PAREBEN_OK;
+}
+
+static int ensure_workspace(pareben_ctx *c, int blocks)
+{
+    c->L = ws_layout(c->p, c->cap);
+    const size_t need = c->L.bytes * (size_t)blocks;
+    if (need > c->ws_bytes) {
+        if (c->d_ws) { hipFree(c->d_ws); c->d_ws = nullptr; c->ws_bytes = 0; }
+        hipError_t e = hipMalloc((void **)&c->d_ws, need);
+        if (e != hipSuccess) return fail(PAREBEN_ENOMEM, "workspace hipMalloc", e);
+        c->ws_bytes = need;
+    }
+    c->ws_blocks = blocks;
+    return PAREBEN_OK;
+}
+
+extern "C" int pareben_ctx_run(pareben_ctx *c, int n_cells, const double *alpha, const double *lambda,
+                               double *fold_err, int32_t *status, int64_t *counters)
+{
+    if (!c || n_cells < 1 || !alpha || !lambda || !fold_err) return fail(PAREBEN_EINVAL, "bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    const int nF = c->n_folds, n_units = n_cells * nF;
+    // heaviest first: small lambda (then small alpha) fits carry the largest active sets
+    std::vector<int> cells(n_cells);
+    std::iota(cells.begin(), cells.end(), 0);
+    std::stable_sort(cells.begin(), cells.end(), [&](int a, int b) {
+        if (lambda[a] != lambda[b]) return lambda[a] < lambda[b];
+        return alpha[a] < alpha[b];
+    });
+    std::vector<int> order(n_units);
+    for (int k = 0; k < n_cells; k++) for (int f = 0; f < nF; f++) order[k * nF + f] = cells[k] * nF + f;
+
+    int occ = 1;
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, gm_cv_kernel, FIT_THREADS, 0));
+    if (occ < 1) occ = 1;
+    int blocks = std::min(n_units, c->n_cu * occ);
+    int rc = ensure_workspace(c, blocks);
+    if (rc) return rc;
+
+    double *d_alpha = nullptr, *d_lambda = nullptr, *d_err = nullptr;
+    int *d_order = nullptr, *d_queue = nullptr, *d_status = nullptr;
+    long long *d_cnt = nullptr;
+    auto cleanup = [&]() { hipFree(d_alpha); hipFree(d_lambda); hipFree(d_err); hipFree(d_order); hipFree(d_queue); hipFree(d_status); hipFree(d_cnt); };
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(PAREBEN_EHIP, #x, e_); } } while (0)
+    CK(dmalloc(&d_alpha, (size_t)n_cells)); CK(dmalloc(&d_lambda, (size_t)n_cells));
+    CK(dmalloc(&d_err, (size_t)n_units)); CK(dmalloc(&d_order, (size_t)n_units));
+    CK(dmalloc(&d_queue, (size_t)1)); CK(dmalloc(&d_status, (size_t)n_units));
+    if (counters) CK(dmalloc(&d_cnt, (size_t)n_units * PAREBEN_NCOUNTERS));
+    CK(hipMemcpyAsync(d_alpha, alpha, sizeof(double) * n_cells, hipMemcpyHostToDevice, c->stream));
+    CK(hipMemcpyAsync(d_lambda, lambda, sizeof(double) * n_cells, hipMemcpyHostToDevice, c->stream));
+    CK(hipMemcpyAsync(d_order, order.data(), sizeof(int) * n_units, hipMemcpyHostToDevice, c->stream));
+    CK(hipMemsetAsync(d_queue, 0, sizeof(int), c->stream));
+    CK(hipMemsetAsync(d_err, 0xFF, sizeof(double) * n_units, c->stream));       // NaN-poison
+    CK(hipMemsetAsync(d_status, 0xFF, sizeof(int) * n_units, c->stream));
+
+    CK(hipEventRecord(c->ev[0], c->stream));
+    rc = prepare_folds(c);
+    if (rc) { cleanup(); return rc; }
+    CK(hipEventRecord(c->ev[1], c->stream));
+
+    CvParams P;
+    P.folds = c->d_folds; P.alpha = d_alpha; P.lambda = d_lambda; P.order = d_order; P.queue = d_queue;
+    P.fold_err = d_err; P.status = d_status; P.counters = d_cnt; P.ws = c->d_ws;
+    P.ws_stride = c->L.bytes; P.offK = c->L.offK; P.offSig = c->L.offSig; P.offM = c->L.offM;
+    P.K = c->p; P.cap = c->cap; P.n_folds = nF; P.n_units = n_units;
+    hipLaunchKernelGGL(gm_cv_kernel, dim3(blocks), dim3(FIT_THREADS), 0, c->stream, P);
+    CK(hipGetLastError());
+    CK(hipEventRecord(c->ev[2], c->stream));
+
+    CK(hipMemcpyAsync(fold_err, d_err, sizeof(double) * n_units, hipMemcpyDeviceToHost, c->stream));
+    std::vector<int> st(n_units);
+    CK(hipMemcpyAsync(st.data(), d_status, sizeof(int) * n_units, hipMemcpyDeviceToHost, c->stream));
+    if (counters) CK(hipMemcpyAsync(counters, d_cnt, sizeof(int64_t) * (size_t)n_units * PAREBEN_NCOUNTERS, hipMemcpyDeviceToHost, c->stream));
+    CK(hipEventRecord(c->ev[3], c->stream));
+    CK(hipStreamSynchronize(c->stream));
+    if (status) for (int i = 0; i < n_units; i++) status[i] = st[i];
+    float a = 0, b = 0, t = 0;
+    CK(hipEventElapsedTime(&a, c->ev[0], c->ev[1]));
+    CK(hipEventElapsedTime(&b, c->ev[1], c->ev[2]));
+    CK(hipEventElapsedTime(&t, c->ev[0], c->ev[3]));
+    c->last_ms[0] = a; c->last_ms[1] = b; c->last_ms[2] = t;
+    c->launch_info[0] = blocks; c->launch_info[1] = FIT_THREADS; c->launch_info[2] = c->cap;
+    c->launch_info[3] = (int64_t)(c->L.bytes >> 10);
+#undef CK
+    cleanup();
+    return PAREBEN_OK;
+}
+
+extern "C" int pareben_ctx_last_timing(pareben_ctx *c, double ms[3])
+{
+    if (!c || !ms) return fail(PAREBEN_EINVAL, "bad argument");
+    ms[0] = c->last_ms[0]; ms[1] = c->last_ms[1]; ms[2] = c->last_ms[2];
+    return PAREBEN_OK;
+}
+
+extern "C" int pareben_ctx_launch_info(pareben_ctx *c, int64_t info[4])
+{
+    if (!c || !info) return fail(PAREBEN_EINVAL, "bad argument");
+    for (int i = 0; i < 4; i++) info[i] = c->launch_info[i];
+    return PAREBEN_OK;
+}
+
+extern "C" int pareben_cv_grid(const double *basis, int n, int p, const double *target,
+                               const int32_t *fold_id, int n_folds, const double *alpha,
+                               const double *lambda, int n_cells, int epis, int prior, int device,
+                               double *fold_err, int32_t *status, int64_t *counters)
+{
+    pareben_ctx *c = nullptr;
+    int rc = pareben_ctx_create(&c, device, basis, n, p, target, fold_id, n_folds, prior, epis, 0);
+    if (rc) return rc;
+    rc = pareben_ctx_run(c, n_cells, alpha, lambda, fold_err, status, counters);
+    pareben_ctx_destroy(c);
+    return rc;
+}
+
+extern "C" int pareben_fit_gaussian(const double *basis, const double *target, double lambda, double alpha,
+                                    double *Beta, double *wald, double *intercept, int n, int k,
+                                    int verbose, double *residual, int device, int64_t *counters)
+{
+    (void)verbose;
+    if (!basis || !target || !Beta || !wald || !intercept || !residual || n < 2 || k < 1) return fail(PAREBEN_EINVAL, "bad argument");
+    // one pseudo-fold whose training set is every row and whose held-out set is empty
+    std::vector<std::vector<int>> tr(1), te(1);
+    tr[0].resize(n);
+    std::iota(tr[0].begin(), tr[0].end(), 0);
+    pareben_ctx *c = nullptr;
+    int rc = ctx_create_impl(&c, device, basis, n, k, target, tr, te, PAREBEN_PRIOR_GAUSSIAN, 0, 0);
+    if (rc) return rc;
+    auto bail = [&](int code) { pareben_ctx_destroy(c); return code; };
+    if (hipSetDevice(c->device) != hipSuccess) return bail(fail(PAREBEN_EHIP, "hipSetDevice"));
+    rc = prepare_folds(c);
+    if (rc) return bail(rc);
+    rc = ensure_workspace(c, 1);
+    if (rc) return bail(rc);
+    double *d_beta = nullptr, *d_sc = nullptr; int *d_st = nullptr; long long *d_cnt = nullptr;
+    auto cleanup = [&]() { hipFree(d_beta); hipFree(d_sc); hipFree(d_st); hipFree(d_cnt); };
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return bail(fail(PAREBEN_EHIP, #x, e_)); } } while (0)
+    CK(dmalloc(&d_beta, (size_t)k * 4)); CK(dmalloc(&d_sc, (size_t)3)); CK(dmalloc(&d_st, (size_t)1));
+    CK(dmalloc(&d_cnt, (size_t)PAREBEN_NCOUNTERS));
+    CK(hipStreamSynchronize(c->stream));
+    FitParams P;
+    CK(hipMemcpy(&P.F, c->d_folds, sizeof(FoldDev), hipMemcpyDeviceToHost));
+    P.lambda = lambda; P.alpha = alpha; P.Beta = d_beta; P.scalars = d_sc; P.status = d_st; P.counters = d_cnt;
+    P.ws = c->d_ws; P.offK = c->L.offK; P.offSig = c->L.offSig; P.offM = c->L.offM; P.K = k; P.cap = c->cap;
+    hipLaunchKernelGGL(gm_fit_kernel, dim3(1), dim3(FIT_THREADS), 0, c->stream, P);
+    CK(hipGetLastError());
+    CK(hipStreamSynchronize(c->stream));
+    double sc[3]; int st = 0;
+    CK(hipMemcpy(Beta, d_beta, sizeof(double) * (size_t)k * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(sc, d_sc, sizeof sc, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(&st, d_st, sizeof st, hipMemcpyDeviceToHost));
+    if (counters) CK(hipMemcpy(counters, d_cnt, sizeof(int64_t) * PAREBEN_NCOUNTERS, hipMemcpyDeviceToHost));
+#undef CK
+    *wald = sc[0]; *intercept = sc[1]; *residual = sc[2];
+    cleanup();
+    pareben_ctx_destroy(c);
+    return (st & ST_ABORT) ? fail(PAREBEN_EHIP, "fit aborted (see status bits in counters[11])") : PAREBEN_OK;
+}

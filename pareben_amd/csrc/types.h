@@ -1,0 +1,47 @@
+// types.h -- plain structs shared by the host API and the device code.
+#pragma once
+#include <stdint.h>
+
+// Per-fold read-only data in HBM.  All matrices are column-major with the training (or test)
+// rows of that fold compacted in their original order, so every column is one contiguous,
+// coalesced run.
+struct FoldDev {
+    const double *X;        // N   x K  training design
+    const double *y;        // N        training target
+    const double *Xte;      // nte x K  held-out design
+    const double *yte;      // nte
+    const double *scale;    // K  |x_i| (1 where the column is all zero)     MainEff.c:87-99
+    const double *rscale;   // K  1/scale
+    const double *bt0;      // K  x_i.y / scale_i
+    const double *cs;       // K  x_i.1 / scale_i
+    const double *G;        // K x K normalised Gram, row u: G[u*K+i] = x_i.(x_u/scale_u)/scale_i
+    double ymean;           // sum(y)/N                                       MainEff.c:145-147
+    double varY;            // unbiased variance of y                         MainEff.c:152
+    int N, nte;
+};
+
+// Per-fit counters (SURVEY.md 8(d) accounting); same meaning as oracle/eben_oracle.h.
+struct FitCounters {
+    int64_t n_outer, n_inner, n_add, n_del, n_reest, n_fullstat;
+    int64_t sum_m_action, sum_m_full, sum_m2_full, m_final, m_max, status;
+};
+#define PAREBEN_NCOUNTERS 12
+
+enum {
+    ST_OVERFLOW = 1,      // active set reached the workspace capacity
+    ST_CHOLESKY = 2,      // Hessian not positive definite
+    ST_STALE = 4,         // reference's stale-index delete path taken (SURVEY.md hard parts)
+    ST_ABORT = 8          // fit stopped early (a state the reference leaves undefined)
+};
+
+// Per-workgroup scratch in HBM (one slot per resident workgroup).
+struct GmWork {
+    double *Sin, *Qin, *Sout, *Qout, *dml, *aroot, *bt;   // K each
+    int *upos, *todo;                                      // K each
+    signed char *act;                                      // K
+    double *Sig, *H;                                       // cap x cap, column-major, ld = cap
+    double *A, *mu, *gam, *v1, *v2, *v3, *v4;              // cap+1 each
+    int *used;                                             // cap+1
+    double *e;                                             // max(N) scratch
+    int cap, ld;
+};

@@ -1,0 +1,107 @@
+"""Host-side counterparts of parEBEN's R helpers around the fit grid.
+
+Same names, argument meaning and results as the R functions they mirror:
+
+* ``GetLambdaMax`` / ``BuildGrid``  -- R/BuildGrid.R:5-52
+* ``AssignToFolds``                 -- R/AssignToFolds.R:6-19 (``set.seed(1)`` + ``sample``)
+* ``summarise_cv``                  -- the dplyr summary and first-minimum arg-min of
+                                        R/CrossValidate.R:72-85 / :93-101
+
+These are O(grid) or one O(n*p) pass and stay on the host, exactly as in the reference where
+they run in the R master process; the fits they parameterise run on the GPU.
+"""
+import math
+import numpy as np
+
+from .rlang import RRandom, r_seq_by, r_sd
+
+
+def _as_matrix(BASIS):
+    X = np.asarray(BASIS, dtype=np.float64)
+    if X.ndim != 2:
+        raise ValueError("BASIS must be a 2-d matrix (rows = samples, columns = features)")
+    return X
+
+
+def GetLambdaMax(BASIS, Target, Epis="no"):
+    """R/BuildGrid.R:5-32.  max(log 1.1, max_j x_j.response/|x_j|); with Epis="yes" also all
+    pairs x_i*x_j, correlated with the centred but *un-normalised* target."""
+    X = _as_matrix(BASIS)
+    yv = np.asarray(Target, dtype=np.float64).reshape(-1)
+    K = X.shape[1]
+    lam = math.log(1.1)
+    centred = yv - yv.mean()
+    response = centred / math.sqrt(float(np.sum(centred * centred)))
+    norms = np.sqrt(np.sum(X * X, axis=0))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        cor = (X / norms).T @ response
+    for c in cor:                       # NaN (all-zero column) never compares greater, as in R
+        if c > lam:
+            lam = float(c)
+    if Epis == "yes":
+        for i in range(K - 1):
+            prod = X[:, i:i + 1] * X[:, i + 1:]
+            nrm = np.sqrt(np.sum(prod * prod, axis=0))
+            with np.errstate(divide="ignore", invalid="ignore"):
+                c2 = (prod / nrm).T @ centred
+            for c in c2:
+                if c > lam:
+                    lam = float(c)
+    return lam
+
+
+def BuildGrid(BASIS, Target, nFolds, Epis="no", nAlpha=20, nLambda=20):
+    """R/BuildGrid.R:34-52.  Returns (alpha, lambda) arrays of the expanded grid, alpha fastest
+    (``expand.grid(alpha = Alpha, lambda = Lambda)``).  nAlpha/nLambda default to the reference's
+    hard-wired 20 x 20; other sizes are an extension: lambda keeps the
+    10*lambda_max ... 0.001*10*lambda_max log range split in nLambda-1 steps, alpha is
+    seq(1, by = -1/nAlpha)."""
+    lambda_max = GetLambdaMax(BASIS, Target, Epis) * 10
+    lambda_min = math.log(0.001 * lambda_max)
+    step = (math.log(lambda_max) - lambda_min) / (nLambda - 1)
+    Lambda = np.exp(r_seq_by(math.log(lambda_max), lambda_min, -step))
+    if nAlpha == 20:
+        Alpha = r_seq_by(1.0, 0.05, -0.05)
+    else:
+        Alpha = r_seq_by(1.0, 1.0 / nAlpha, -1.0 / nAlpha)
+    alpha = np.tile(Alpha, len(Lambda))
+    lam = np.repeat(Lambda, len(Alpha))
+    return alpha, lam
+
+
+def AssignToFolds(BASIS, nFolds=0, foldId=0, sample_kind="Rejection"):
+    """R/AssignToFolds.R:6-19: ``set.seed(1)`` then a permutation of rep(1:nFolds, ...).
+    ``sample_kind`` picks R's sampler generation ("Rejection": R >= 3.6 default; "Rounding":
+    what R < 3.6 used, e.g. the authors' R 3.5.0 runs)."""
+    N = _as_matrix(BASIS).shape[0]
+    fid = np.atleast_1d(np.asarray(foldId))
+    if fid.size == N:
+        return fid.astype(np.int32)
+    rng = RRandom(1, sample_kind)
+    base = list(range(1, nFolds + 1)) * (N // nFolds)
+    if N % nFolds != 0:
+        base = base + list(range(1, N % nFolds + 1))
+    return np.asarray(rng.sample(base), dtype=np.int32)
+
+
+def summarise_cv(alpha, lam, fold_err, nFolds, prior="gaussian"):
+    """group_by(alpha, lambda) %>% summarise(SE = sd/sqrt(nFolds), MSE = mean) with rows sorted
+    alpha ascending then lambda ascending, then which.min -> first minimum in that order
+    (R/CrossValidate.R:72-80).  For the binomial prior the summary column is
+    Likelihood = -mean(logL) and the arg-min is taken on it (the evident intent; the reference
+    indexes a non-existent MSE column there).
+    Returns (alpha_sorted, lambda_sorted, SE, err, index_of_optimum)."""
+    alpha = np.asarray(alpha, dtype=np.float64)
+    lam = np.asarray(lam, dtype=np.float64)
+    E = np.asarray(fold_err, dtype=np.float64).reshape(len(alpha), nFolds)
+    order = np.lexsort((lam, alpha))
+    se = np.array([r_sd(E[c]) / math.sqrt(nFolds) for c in order])
+    mean = np.array([float(np.mean(E[c])) for c in order])
+    err = mean if prior == "gaussian" else -mean
+    idx = -1
+    best = math.inf
+    for i, v in enumerate(err):         # which.min: first minimum, NaN skipped
+        if v < best:
+            best = v
+            idx = i
+    return alpha[order], lam[order], se, err, idx

@@ -1,0 +1,129 @@
+// gm_emul.cpp -- TEST INFRASTRUCTURE ONLY.  Compiles the device source of the Gaussian fit
+// (pareben_amd/csrc/gm_fit.h) for the CPU with one "thread" per workgroup (PAREBEN_HOST_EMUL) so
+// that tests can compare its control flow and results with the oracle without a GPU.  The
+// shipped library never links this and has no CPU fallback.
+#define PAREBEN_HOST_EMUL 1
+#include <vector>
+#include <cmath>
+#include <cstring>
+#include <cstdlib>
+#include "../../pareben_amd/csrc/types.h"
+#include "../../pareben_amd/csrc/blk.h"
+#include "../../pareben_amd/csrc/gm_fit.h"
+
+namespace {
+struct Fold {
+    int N, nte;
+    std::vector<double> X, y, Xte, yte, scale, rscale, bt0, cs, G;
+    double ymean, varY;
+};
+
+// CPU stand-ins for split_kernel / colstats_kernel / ystats_kernel / gram_kernel
+void prepare(Fold &F, const double *basis, int n, int p, const double *y, const int *fold_id, int f)
+{
+    std::vector<int> tr, te;
+    for (int i = 0; i < n; i++) (fold_id[i] == f + 1 ? te : tr).push_back(i);
+    F.N = (int)tr.size(); F.nte = (int)te.size();
+    F.X.resize((size_t)F.N * p); F.Xte.resize((size_t)F.nte * p + 1); F.y.resize(F.N); F.yte.resize(F.nte + 1);
+    for (int j = 0; j < p; j++) {
+        for (int r = 0; r < F.N; r++) F.X[(size_t)j * F.N + r] = basis[(size_t)j * n + tr[r]];
+        for (int r = 0; r < F.nte; r++) F.Xte[(size_t)j * F.nte + r] = basis[(size_t)j * n + te[r]];
+    }
+    for (int r = 0; r < F.N; r++) F.y[r] = y[tr[r]];
+    for (int r = 0; r < F.nte; r++) F.yte[r] = y[te[r]];
+    F.scale.resize(p); F.rscale.resize(p); F.bt0.resize(p); F.cs.resize(p); F.G.resize((size_t)p * p);
+    for (int j = 0; j < p; j++) {
+        double q = 0, xy = 0, x1 = 0;
+        for (int h = 0; h < F.N; h++) { double v = F.X[(size_t)j * F.N + h]; q += v * v; xy += v * F.y[h]; x1 += v; }
+        if (q == 0) q = 1;
+        double s = std::sqrt(q);
+        F.scale[j] = s; F.rscale[j] = 1 / s; F.bt0[j] = xy / s; F.cs[j] = x1 / s;
+    }
+    double s = 0; for (int h = 0; h < F.N; h++) s += F.y[h];
+    F.ymean = s / F.N;
+    double v = 0; for (int h = 0; h < F.N; h++) { double d = F.y[h] - F.ymean; v += d * d; }
+    F.varY = v / (F.N - 1);
+    for (int u = 0; u < p; u++)
+        for (int i = 0; i < p; i++) {
+            double a = 0;
+            for (int h = 0; h < F.N; h++) a += F.X[(size_t)i * F.N + h] * (F.X[(size_t)u * F.N + h] * F.rscale[u]);
+            F.G[(size_t)u * p + i] = a / F.scale[i];
+        }
+}
+
+FoldDev dev_view(const Fold &F)
+{
+    FoldDev D;
+    D.X = F.X.data(); D.y = F.y.data(); D.Xte = F.Xte.data(); D.yte = F.yte.data();
+    D.scale = F.scale.data(); D.rscale = F.rscale.data(); D.bt0 = F.bt0.data(); D.cs = F.cs.data();
+    D.G = F.G.data(); D.ymean = F.ymean; D.varY = F.varY; D.N = F.N; D.nte = F.nte;
+    return D;
+}
+
+struct Work {
+    std::vector<double> kd, sig, md; std::vector<int> ki, used; std::vector<signed char> act;
+    GmWork W;
+    Work(int K, int cap)
+    {
+        kd.assign((size_t)7 * K, 0); ki.assign((size_t)2 * K, 0); act.assign(K, 0);
+        sig.assign((size_t)2 * cap * cap, 0); md.assign((size_t)7 * (cap + 1), 0); used.assign(cap + 1, 0);
+        double *d = kd.data();
+        W.Sin = d; d += K; W.Qin = d; d += K; W.Sout = d; d += K; W.Qout = d; d += K; W.dml = d; d += K; W.aroot = d; d += K; W.bt = d;
+        W.upos = ki.data(); W.todo = ki.data() + K; W.act = act.data();
+        W.Sig = sig.data(); W.H = sig.data() + (size_t)cap * cap;
+        d = md.data(); int c1 = cap + 1;
+        W.A = d; d += c1; W.mu = d; d += c1; W.gam = d; d += c1; W.v1 = d; d += c1; W.v2 = d; d += c1; W.v3 = d; d += c1; W.v4 = d;
+        W.used = used.data(); W.e = nullptr; W.cap = cap; W.ld = cap;
+    }
+};
+}  // namespace
+
+extern "C" int emul_default_cap(int K)
+{
+    long cap = (long)(1e7 / K);
+    if (cap > K) cap = K;
+    if (cap > 2048) cap = 2048;
+    if (cap < 2) cap = 2;
+    return (int)cap;
+}
+
+// same contract as pareben_cv_grid (gaussian, main effects)
+extern "C" int emul_gm_cv_grid(const double *basis, int n, int p, const double *y, const int *fold_id, int n_folds,
+                               const double *alpha, const double *lambda, int n_cells,
+                               double *fold_err, int *status, long long *counters)
+{
+    const int cap = emul_default_cap(p);
+    std::vector<Fold> folds(n_folds);
+    for (int f = 0; f < n_folds; f++) prepare(folds[f], basis, n, p, y, fold_id, f);
+    Work ws(p, cap);
+    Blk B; B.tid = 0; B.nthr = 1; B.lane = 0; B.wave = 0; B.nwave = 1; B.red = nullptr; B.ired = nullptr;
+    for (int c = 0; c < n_cells; c++)
+        for (int f = 0; f < n_folds; f++) {
+            FoldDev F = dev_view(folds[f]);
+            GmScalars S; FitCounters cnt; S.c = &cnt;
+            gm_fit(B, F, ws.W, p, lambda[c], alpha[c], S, nullptr, nullptr);
+            const int u = c * n_folds + f;
+            fold_err[u] = gm_fold_sse(B, F, ws.W, S);
+            if (status) status[u] = S.status;
+            if (counters) std::memcpy(counters + (size_t)u * PAREBEN_NCOUNTERS, &cnt, sizeof cnt);
+        }
+    return 0;
+}
+
+// one fit on all rows; out = {intercept, beta(noise precision), M}; used/mu sized >= cap
+extern "C" int emul_gm_fit(const double *X, const double *y, int n, int p, double lambda, double alpha,
+                           double *out, int *used, double *mu, double *sigdiag, long long *counters)
+{
+    std::vector<int> fid(n, 2);
+    Fold F; prepare(F, X, n, p, y, fid.data(), 0);
+    const int cap = emul_default_cap(p);
+    Work ws(p, cap);
+    Blk B; B.tid = 0; B.nthr = 1; B.lane = 0; B.wave = 0; B.nwave = 1; B.red = nullptr; B.ired = nullptr;
+    FoldDev D = dev_view(F);
+    GmScalars S; FitCounters cnt; S.c = &cnt;
+    gm_fit(B, D, ws.W, p, lambda, alpha, S, nullptr, nullptr);
+    out[0] = S.b; out[1] = S.beta; out[2] = S.M;
+    for (int i = 0; i < S.M; i++) { used[i] = ws.W.used[i]; mu[i] = ws.W.mu[i] / F.scale[ws.W.used[i]]; sigdiag[i] = ws.W.Sig[(size_t)i * cap + i] / (F.scale[ws.W.used[i]] * F.scale[ws.W.used[i]]); }
+    if (counters) std::memcpy(counters, &cnt, sizeof cnt);
+    return S.status;
+}
