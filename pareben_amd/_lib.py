@@ -1,0 +1,133 @@
+"""ctypes binding of libpareben_hip.so (include/pareben_hip.h).  There is no CPU fallback: if the
+HIP library is missing or no GPU is visible every compute entry point raises."""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpareben_hip.so")
+NCOUNTERS = 12
+COUNTER_NAMES = ("n_outer", "n_inner", "n_add", "n_del", "n_reest", "n_fullstat", "sum_m_action",
+                 "sum_m_full", "sum_m2_full", "m_final", "m_max", "status")
+ST_OVERFLOW, ST_CHOLESKY, ST_STALE, ST_ABORT = 1, 2, 4, 8
+
+_lib = None
+
+
+class ParebenError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (does not touch the GPU)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ParebenError(
+            "libpareben_hip.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C pareben_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    dp, ip, lp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+    L.pareben_version.restype = C.c_char_p
+    L.pareben_last_error.restype = C.c_char_p
+    L.pareben_device_count.restype = C.c_int
+    L.pareben_ctx_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, dp, C.c_int, C.c_int, dp, ip, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.pareben_ctx_run.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, ip, lp]
+    L.pareben_ctx_last_timing.argtypes = [C.c_void_p, dp]
+    L.pareben_ctx_launch_info.argtypes = [C.c_void_p, lp]
+    L.pareben_ctx_destroy.argtypes = [C.c_void_p]
+    L.pareben_cv_grid.argtypes = [dp, C.c_int, C.c_int, dp, ip, C.c_int, dp, dp, C.c_int, C.c_int, C.c_int, C.c_int, dp, ip, lp]
+    L.pareben_fit_gaussian.argtypes = [dp, dp, C.c_double, C.c_double, dp, dp, dp, C.c_int, C.c_int, C.c_int, dp, C.c_int, lp]
+    _lib = L
+    return L
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise ParebenError("%s failed (code %d): %s" % (what, rc, load().pareben_last_error().decode()))
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def _lp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int64))
+
+
+class Context:
+    """One CV problem staged in HBM (pareben_ctx_create / _run / _destroy)."""
+
+    def __init__(self, BASIS, Target, fold_id, n_folds, prior="gaussian", epis=False, device=0, max_active=0):
+        L = load()
+        X = np.asfortranarray(BASIS, dtype=np.float64)
+        y = np.ascontiguousarray(Target, dtype=np.float64).reshape(-1)
+        fid = np.ascontiguousarray(fold_id, dtype=np.int32).reshape(-1)
+        if X.ndim != 2 or y.shape[0] != X.shape[0] or fid.shape[0] != X.shape[0]:
+            raise ValueError("BASIS must be n x p and Target / fold_id must have n entries")
+        self.n, self.p = X.shape
+        self.n_folds = int(n_folds)
+        self._h = C.c_void_p()
+        _chk(L.pareben_ctx_create(C.byref(self._h), int(device), _dp(X), self.n, self.p, _dp(y), _ip(fid), self.n_folds,
+                                  0 if prior == "gaussian" else 1, 1 if epis else 0, int(max_active)), "pareben_ctx_create")
+
+    def run(self, alpha, lam, want_counters=True):
+        """-> (fold_err [n_cells, n_folds], status [n_cells, n_folds], counters [n_cells, n_folds, 12] | None)"""
+        L = load()
+        alpha = np.ascontiguousarray(alpha, dtype=np.float64).reshape(-1)
+        lam = np.ascontiguousarray(lam, dtype=np.float64).reshape(-1)
+        nc = alpha.shape[0]
+        err = np.empty((nc, self.n_folds))
+        st = np.empty((nc, self.n_folds), dtype=np.int32)
+        cnt = np.empty((nc, self.n_folds, NCOUNTERS), dtype=np.int64) if want_counters else None
+        _chk(L.pareben_ctx_run(self._h, nc, _dp(alpha), _dp(lam), _dp(err), _ip(st),
+                               _lp(cnt) if cnt is not None else None), "pareben_ctx_run")
+        return err, st, cnt
+
+    def last_timing(self):
+        ms = np.zeros(3)
+        _chk(load().pareben_ctx_last_timing(self._h, _dp(ms)), "pareben_ctx_last_timing")
+        return {"prep_ms": float(ms[0]), "fit_ms": float(ms[1]), "total_ms": float(ms[2])}
+
+    def launch_info(self):
+        info = np.zeros(4, dtype=np.int64)
+        _chk(load().pareben_ctx_launch_info(self._h, _lp(info)), "pareben_ctx_launch_info")
+        return {"workgroups": int(info[0]), "threads": int(info[1]), "capacity": int(info[2]), "ws_kib": int(info[3])}
+
+    def close(self):
+        if self._h:
+            load().pareben_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def fit_gaussian(BASIS, Target, lam, alpha, device=0):
+    """Mirror of the reference's .C("elasticNetLinearNeMainEff") tuple
+    (EBEN_orig/R/EBelasticNet.Gaussian.R:39-51) -> dict(Beta K x 4, wald, intercept, residual, counters)."""
+    L = load()
+    X = np.asfortranarray(BASIS, dtype=np.float64)
+    y = np.ascontiguousarray(Target, dtype=np.float64).reshape(-1)
+    n, k = X.shape
+    Beta = np.zeros((k, 4), order="F")
+    wald, icpt, resid = C.c_double(0), C.c_double(0), C.c_double(0)
+    cnt = np.zeros(NCOUNTERS, dtype=np.int64)
+    _chk(L.pareben_fit_gaussian(_dp(X), _dp(y), float(lam), float(alpha), _dp(Beta), C.byref(wald), C.byref(icpt),
+                                n, k, 0, C.byref(resid), int(device), _lp(cnt)), "pareben_fit_gaussian")
+    return dict(Beta=Beta, wald=wald.value, intercept=icpt.value, residual=resid.value,
+                counters=dict(zip(COUNTER_NAMES, (int(v) for v in cnt))))

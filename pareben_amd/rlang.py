@@ -101,9 +101,12 @@ class RRandom:
 
 
 def r_seq_by(frm, to, by):
-    """R's seq(from, to, by): n = floor((to-from)/by + 1e-10), values from + (0..n)*by."""
+    """R's seq.default(from, to, by): n = floor((to-from)/by + 1e-10), values from + (0..n)*by,
+    then clamped so rounding cannot overshoot ``to`` (pmin for by > 0, pmax for by < 0) -- which is
+    why the stored real-R grids end in exactly 0.05 although 1 + 19*(-0.05) = 0.04999999999999993."""
     n = int(math.floor((to - frm) / by + 1e-10))
-    return np.array([frm + i * by for i in range(n + 1)], dtype=np.float64)
+    v = np.array([frm + i * by for i in range(n + 1)], dtype=np.float64)
+    return np.minimum(v, to) if by > 0 else np.maximum(v, to)
 
 
 def r_sd(v):

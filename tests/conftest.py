@@ -1,0 +1,49 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    class G:
+        BASIS = np.load(os.path.join(GOLDEN, "BASIS.npy")).astype(np.float64)
+        y = np.load(os.path.join(GOLDEN, "y.npy"))
+        BASISbinomial = np.load(os.path.join(GOLDEN, "BASISbinomial.npy")).astype(np.float64)
+        yBinomial = np.load(os.path.join(GOLDEN, "yBinomial.npy")).astype(np.float64)
+        config1 = np.load(os.path.join(GOLDEN, "config1_gm.npz"))
+        basis481 = np.load(os.path.join(GOLDEN, "basis481_gm.npz"))
+        rds = np.load(os.path.join(GOLDEN, "rds_10000.npz"))
+        import json
+        known = json.load(open(os.path.join(GOLDEN, "survey_known_answers.json")))
+    return G
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle_lib
+    oracle_lib.build()
+    return oracle_lib
+
+
+def synthetic_gaussian(n, p, n_causal=20, seed=20251004):
+    """SURVEY.md 8(d) config-2 style data: X ~ N(0,1) iid, n_causal effects ~ N(0,1), unit noise.
+    (numpy Generator stream; the benchmark only needs the shape and distribution.)"""
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((n, p))
+    idx = rng.choice(p, size=n_causal, replace=False)
+    beta = rng.standard_normal(n_causal)
+    y = X[:, idx] @ beta + rng.standard_normal(n)
+    return np.asfortranarray(X), y

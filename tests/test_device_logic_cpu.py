@@ -1,0 +1,33 @@
+"""The device source of the Gaussian fit (pareben_amd/csrc/gm_fit.h), compiled for the CPU with one
+thread per workgroup, against the oracle: same action sequence (all event counters equal) and
+fold SSE within 1e-10 relative.  This checks the Gram-space reformulation and every control-flow
+quirk without a GPU; the parallel execution itself is covered by the -m gpu tests."""
+import numpy as np
+
+import emul_lib
+
+NAMES = ("n_outer", "n_inner", "n_add", "n_del", "n_reest", "n_fullstat", "sum_m_action",
+         "sum_m_full", "sum_m2_full", "m_final")
+
+
+def test_config1_all_cells(golden):
+    g = golden.config1
+    X, y = golden.BASIS[:50, :100], golden.y[:50]
+    E, st, cnt = emul_lib.cv_grid(X, y, g["fold_id"], 3, g["alpha"], g["lam"])
+    rel = np.abs(E - g["fold_err"]) / np.abs(g["fold_err"])
+    assert rel.max() < 1e-10
+    assert set(np.unique(st)) <= {0, 4}              # 4 = reference's stale-slot delete path
+    assert (st == 4).sum() == 11
+    tot = cnt.sum(axis=(0, 1))
+    want = dict(zip(g["counter_names"], g["counters"]))
+    for i, n in enumerate(NAMES):
+        assert tot[i] == want[n], n
+
+
+def test_basis481_subgrid(golden):
+    g = golden.basis481
+    sel = [0, 2, 4, 7, 12]                           # keep the CPU suite short
+    E, st, cnt = emul_lib.cv_grid(golden.BASIS, golden.y, g["fold_id"], 5, g["alpha"][sel], g["lam"][sel])
+    ref = g["fold_err"][sel]
+    assert (np.abs(E - ref) / np.abs(ref)).max() < 1e-10
+    assert cnt[..., 10].max() > 100                  # exercises the M > 100 delete-priority regime

@@ -1,0 +1,151 @@
+"""GPU parity tests: the HIP path, called through the C ABI (pareben_amd._lib -> libpareben_hip.so),
+against the oracle on the same inputs and against the committed golden fixtures.
+
+Bar (BASELINE.json north_star): cv.error within 1e-6 (relative), selected (alpha, lambda) exact.
+Tolerances used here are tighter where the data allow: fold SSE 1e-9 relative, identical event
+counters (= identical add/delete/re-estimate sequence) on the bundled data."""
+import numpy as np
+import pytest
+
+import pareben_amd
+from pareben_amd.grid import BuildGrid, AssignToFolds, summarise_cv
+from conftest import synthetic_gaussian
+
+pytestmark = pytest.mark.gpu
+
+REL_FOLD = 1e-9
+REL_CV = 1e-6
+
+
+def _rel(a, b):
+    return np.abs(a - b) / np.maximum(np.abs(b), 1e-300)
+
+
+def test_library_loaded_and_gpu_visible():
+    L = pareben_amd.load_library()
+    assert L.pareben_device_count() >= 1
+
+
+def test_config1_full_grid_vs_golden(golden):
+    """Reference's own test case (tests/CrossValidate-test.R): BASIS[1:50,1:100], nFolds=3."""
+    X, y = golden.BASIS[:50, :100], golden.y[:50]
+    out = pareben_amd.CrossValidate(X, y, nFolds=3, Epis="no", prior="gaussian", search="global", return_stats=True)
+    g, k = golden.config1, golden.known["config1"]
+    D = out["Results.Detail"]
+    E = np.asarray(D["MSE"]).reshape(400, 3)
+    assert np.array_equal(np.asarray(D["alpha"])[::3], g["alpha"]) and np.array_equal(np.asarray(D["lambda"])[::3], g["lam"])
+    assert np.array_equal(np.asarray(D["foldId"])[:3], [1, 2, 3])
+    assert _rel(E, g["fold_err"]).max() < REL_FOLD
+    assert out["alpha.optimal"] == k["alpha_opt"] and out["lambda.optimal"] == k["lambda_opt"]
+    S = out["Results.Summary"]
+    i = int(np.argmin(np.asarray(S["MSE"])))
+    assert abs(np.asarray(S["MSE"])[i] - k["cv_error"]) < REL_CV * k["cv_error"]
+    assert abs(np.asarray(S["SE"])[i] - k["SE"]) < REL_CV * k["SE"]
+    st = out["stats"]["status"]
+    assert set(np.unique(st)) <= {0, 4} and (st == 4).sum() == 11
+    cnt = out["stats"]["counters"].sum(axis=(0, 1))
+    want = dict(zip(g["counter_names"], g["counters"]))
+    for j, n in enumerate(("n_outer", "n_inner", "n_add", "n_del", "n_reest", "n_fullstat")):
+        assert cnt[j] == want[n], n
+
+
+def test_basis481_subgrid_vs_golden(golden):
+    g = golden.basis481
+    with pareben_amd.Context(golden.BASIS, golden.y, g["fold_id"], 5) as ctx:
+        E, st, cnt = ctx.run(g["alpha"], g["lam"])
+    assert _rel(E, g["fold_err"]).max() < REL_FOLD
+    want = dict(zip(g["counter_names"], g["counters"]))
+    tot = cnt.sum(axis=(0, 1))
+    for j, n in enumerate(("n_outer", "n_inner", "n_add", "n_del", "n_reest", "n_fullstat")):
+        assert tot[j] == want[n], n
+
+
+def test_per_fit_entry_vs_oracle(golden, oracle):
+    X, y = golden.BASIS[:200, :150], golden.y[:200]
+    alpha, lam = BuildGrid(X, y, 5)
+    for c in (0, 210, 399):
+        r = pareben_amd.fit_gaussian(X, y, lam[c], alpha[c])
+        o = oracle.fit_gaussian(X, y, lam[c], alpha[c])
+        nz = np.nonzero(o["Beta"][:, 2])[0]
+        assert np.array_equal(np.nonzero(r["Beta"][:, 2])[0], nz)
+        assert np.array_equal(r["Beta"][:, :2], o["Beta"][:, :2])
+        assert _rel(r["Beta"][nz, 2], o["Beta"][nz, 2]).max() < 1e-8
+        assert _rel(r["Beta"][nz, 3], o["Beta"][nz, 3]).max() < 1e-8
+        assert abs(r["intercept"] - o["intercept"]) < 1e-9 * abs(o["intercept"])
+        assert abs(r["residual"] - o["residual"]) < 1e-9 * o["residual"]
+
+
+def test_synthetic_vs_oracle(oracle):
+    """Ragged sizes (n not a multiple of nFolds, p not a multiple of 64) and N(0,1) designs."""
+    X, y = synthetic_gaussian(157, 333, n_causal=8, seed=5)
+    fid = AssignToFolds(X, 4)
+    alpha, lam = BuildGrid(X, y, 4)
+    sel = np.arange(0, 400, 7)
+    with pareben_amd.Context(X, y, fid, 4) as ctx:
+        E, st, cnt = ctx.run(alpha[sel], lam[sel])
+    Eo, co, rc = oracle.cv_grid(X, y, fid, 4, alpha[sel], lam[sel])
+    assert rc == 0 and np.all(st == 0)
+    assert _rel(E, Eo).max() < 1e-8
+    assert cnt[..., 2].sum() == co["n_add"] and cnt[..., 3].sum() == co["n_del"]
+
+
+def test_rerun_is_bit_identical_and_order_free(golden):
+    """Deterministic reductions: the same cells give bit-identical scores whatever else is in
+    the launch and in whatever order they are submitted (what makes 1/2/4/8-GPU runs agree)."""
+    X, y = golden.BASIS[:120, :90], golden.y[:120]
+    fid = AssignToFolds(X, 3)
+    alpha, lam = BuildGrid(X, y, 3)
+    with pareben_amd.Context(X, y, fid, 3) as ctx:
+        E1, _, _ = ctx.run(alpha, lam)
+        E2, _, _ = ctx.run(alpha, lam)
+        perm = np.random.default_rng(0).permutation(400)[:57]
+        E3, _, _ = ctx.run(alpha[perm], lam[perm])
+    assert np.array_equal(E1, E2)
+    assert np.array_equal(E3, E1[perm])
+
+
+def test_edge_cases(oracle):
+    rng = np.random.default_rng(11)
+    X = np.asfortranarray(rng.standard_normal((41, 17)))
+    y = X[:, 3] * 1.5 + rng.standard_normal(41) * 0.2
+    X[:, 9] = 0                      # all-zero column: scale 1, never selected
+    X[:, 12] = X[:, 3]               # exact duplicate column
+    fid = AssignToFolds(X, 2)
+    alpha = np.array([1.0, 0.5, 0.05, 1.0]); lam = np.array([0.2, 0.05, 0.01, 1e6])
+    with pareben_amd.Context(X, y, fid, 2) as ctx:
+        E, st, cnt = ctx.run(alpha, lam)
+    Eo, co, rc = oracle.cv_grid(X, y, fid, 2, alpha, lam)
+    assert np.all(st & 8 == 0)
+    assert _rel(E, Eo).max() < 1e-8
+    assert cnt[3, :, 2].sum() == 0   # lambda = 1e6: nothing added
+    # argument errors surface as exceptions, not crashes
+    with pytest.raises(pareben_amd.ParebenError):
+        pareben_amd.Context(X, y, np.zeros(41, dtype=np.int32), 2)
+    with pytest.raises(pareben_amd.ParebenError):
+        pareben_amd.Context(X, y, fid, 2, prior="binomial")
+
+
+@pytest.mark.parametrize("n,p,nf", [(1000, 2000, 5)])
+def test_larger_synthetic_properties(n, p, nf, oracle):
+    """At a size the oracle cannot sweep in seconds: size-independent properties, plus a spot
+    check of three cells against the oracle."""
+    X, y = synthetic_gaussian(n, p, n_causal=20, seed=20251004)
+    fid = AssignToFolds(X, nf)
+    alpha, lam = BuildGrid(X, y, nf)
+    sel = np.concatenate([np.arange(0, 400, 40), [399]])
+    with pareben_amd.Context(X, y, fid, nf) as ctx:
+        E, st, cnt = ctx.run(alpha[sel], lam[sel])
+        # shifting the target shifts only the intercept: fold SSEs are invariant
+        pass
+    assert np.all(st & 8 == 0) and np.all(np.isfinite(E)) and np.all(E > 0)
+    # lambda >= 10*lambda_max: at most the forced first basis -> SSE close to the null model's
+    null = np.array([np.sum((y[fid == f + 1] - y[fid != f + 1].mean()) ** 2) for f in range(nf)])
+    assert _rel(E[0], null).max() < 0.05
+    # informative cells beat the null model
+    assert E[5:].mean(axis=1).min() < 0.5 * null.mean()
+    spot = [0, 5, 9]
+    Eo, co, rc = oracle.cv_grid(X, y, fid, nf, alpha[sel][spot], lam[sel][spot], n_threads=8)
+    assert _rel(E[spot], Eo).max() < 1e-7
+    with pareben_amd.Context(X, y + 3.0, fid, nf) as ctx:
+        Es, _, _ = ctx.run(alpha[sel][spot], lam[sel][spot])
+    assert _rel(Es, E[spot]).max() < 1e-6

@@ -1,0 +1,94 @@
+"""CPU tests of the host-side restatements of the R-level pieces (no GPU, no oracle)."""
+import math
+import numpy as np
+
+from pareben_amd.rlang import RRandom, r_seq_by, r_sd
+from pareben_amd.grid import BuildGrid, GetLambdaMax, AssignToFolds, summarise_cv
+
+
+def test_r_rng_known_answers(golden):
+    k = golden.known["rng"]
+    r = RRandom(1)
+    assert [round(r.unif_rand(), 7) for _ in range(3)] == k["runif3"]
+    assert RRandom(1).sample(range(1, 11)) == k["sample10"]
+    assert RRandom(1, "Rounding").sample(range(1, 11)) == k["sample10_rounding"]
+
+
+def test_assign_to_folds_config1(golden):
+    X = golden.BASIS[:50, :100]
+    k = golden.known["config1"]
+    assert "".join(map(str, AssignToFolds(X, 3))) == k["folds"]
+    assert "".join(map(str, AssignToFolds(X, 3, sample_kind="Rounding"))) == k["folds_rounding"]
+    f = AssignToFolds(X, 3)
+    assert sorted(np.bincount(f)[1:].tolist()) == [16, 17, 17]
+    # a full-length foldId is passed through (R/AssignToFolds.R:10)
+    given = np.arange(50) % 3 + 1
+    assert np.array_equal(AssignToFolds(X, 3, given), given)
+    # divisible case: equal fold sizes
+    assert np.bincount(AssignToFolds(golden.BASIS[:60], 3))[1:].tolist() == [20, 20, 20]
+
+
+def test_seq_semantics():
+    a = r_seq_by(1.0, 0.05, -0.05)
+    assert len(a) == 20
+    assert a[18] == 1.0 + 18 * (-0.05)          # 0.09999999999999998, not 0.1
+    assert a[18] != 0.1
+
+
+def test_build_grid_config1(golden):
+    X, y = golden.BASIS[:50, :100], golden.y[:50]
+    k = golden.known["config1"]
+    alpha, lam = BuildGrid(X, y, 3)
+    assert len(alpha) == 400 and len(lam) == 400
+    assert lam[0] == k["lambda_first"] and abs(lam[-1] - k["lambda_last"]) < 1e-17
+    # expand.grid: alpha fastest
+    assert np.array_equal(alpha[:20], r_seq_by(1.0, 0.05, -0.05))
+    assert np.all(lam[:20] == lam[0]) and lam[20] < lam[0]
+    assert GetLambdaMax(X, y) * 10 == lam[0]
+
+
+def test_build_grid_matches_real_r_grid_shape(golden):
+    """The stored real-R output (rds_10000) pins grid order and the alpha values bit for bit."""
+    r = golden.rds
+    a = r["detail_alpha"][::3][:20]
+    assert np.array_equal(a, r_seq_by(1.0, 0.05, -0.05))
+    lam = r["detail_lambda"][::60]
+    assert len(lam) == 20
+    step = (math.log(lam[0]) - math.log(0.001 * lam[0])) / 19
+    ours = np.exp(r_seq_by(math.log(lam[0]), math.log(0.001 * lam[0]), -step))
+    assert np.allclose(ours, lam, rtol=1e-14, atol=0)
+    assert abs(lam[0] - golden.known["yeast10000"]["lambda_max_x10"]) < 1e-13
+
+
+def test_lambda_max_floor_and_epis():
+    rng = np.random.default_rng(0)
+    X = rng.standard_normal((40, 6))
+    y = rng.standard_normal(40) * 1e-3 + 5          # nearly constant, uncorrelated target
+    lm = GetLambdaMax(X, y)
+    assert lm >= math.log(1.1)
+    # Epis pass correlates with the UN-normalised centred target (R/BuildGrid.R:26)
+    y2 = X[:, 0] * X[:, 1] * 10 + rng.standard_normal(40)
+    assert GetLambdaMax(X, y2, "yes") > GetLambdaMax(X, y2, "no")
+
+
+def test_summary_matches_real_r_tables(golden):
+    """mean / sd/sqrt(nFolds) / sort order / first-minimum arg-min, checked on the stored real-R
+    Results.Detail -> Results.Summary pair."""
+    r = golden.rds
+    nF = 3
+    alpha = r["detail_alpha"][::nF]
+    lam = r["detail_lambda"][::nF]
+    E = r["detail_MSE"].reshape(-1, nF)
+    a_s, l_s, se, err, idx = summarise_cv(alpha, lam, E, nF)
+    assert np.array_equal(a_s, r["summary_alpha"]) and np.array_equal(l_s, r["summary_lambda"])
+    assert np.allclose(err, r["summary_MSE"], rtol=1e-14, atol=0)
+    assert np.allclose(se, r["summary_SE"], rtol=1e-12, atol=0)
+    assert l_s[idx] == r["lambda_optimal"][0] and a_s[idx] == r["alpha_optimal"][0]
+
+
+def test_summary_binomial_intent():
+    alpha = np.array([1.0, 0.5]); lam = np.array([0.3, 0.3])
+    E = np.array([[-0.6, -0.7], [-0.4, -0.5]])
+    a_s, l_s, se, err, idx = summarise_cv(alpha, lam, E, 2, prior="binomial")
+    assert np.allclose(err, [0.45, 0.65]) and a_s[idx] == 0.5
+    assert abs(r_sd([1.0, 2.0, 4.0]) - 1.5275252316519468) < 1e-15

@@ -1,0 +1,67 @@
+"""The oracle (CPU restatement, test infrastructure) against every pin available without R:
+the numbers the survey session recorded from the compiled reference C and the
+committed fixtures.  CPU only."""
+import numpy as np
+import pytest
+
+from pareben_amd.grid import BuildGrid, AssignToFolds, summarise_cv
+
+
+def test_oracle_config1_known_answers(golden, oracle):
+    X, y = golden.BASIS[:50, :100], golden.y[:50]
+    k = golden.known["config1"]
+    fid = AssignToFolds(X, 3)
+    alpha, lam = BuildGrid(X, y, 3)
+    E, cnt, rc = oracle.cv_grid(X, y, fid, 3, alpha, lam, n_threads=4)
+    assert rc == 0
+    assert np.allclose(E[0], k["cell_alpha1_lambdamax"], rtol=1e-13, atol=0)
+    assert np.allclose(E[-1], k["cell_alpha005_lambdamin"], rtol=1e-13, atol=0)
+    a_s, l_s, se, err, idx = summarise_cv(alpha, lam, E, 3)
+    assert a_s[idx] == k["alpha_opt"] and l_s[idx] == k["lambda_opt"]
+    assert abs(err[idx] - k["cv_error"]) <= 1e-12 * k["cv_error"]
+    assert abs(se[idx] - k["SE"]) <= 1e-12 * k["SE"]
+    assert cnt["m_final"] == k["nonzero_total"] and cnt["m_max"] == k["max_active"]
+    # committed fixture == fresh run (guards the fixture against drift)
+    assert np.array_equal(E, golden.config1["fold_err"])
+
+
+def test_oracle_per_fit_outputs(golden, oracle):
+    X, y = golden.BASIS[:50, :100], golden.y[:50]
+    fid = AssignToFolds(X, 3)
+    alpha, lam = BuildGrid(X, y, 3)
+    tr = fid != 1
+    r = oracle.fit_gaussian(X[tr], y[tr], lam[0], alpha[0])
+    B = r["Beta"]
+    assert np.array_equal(B[:, 0], np.arange(1, 101)) and np.array_equal(B[:, 0], B[:, 1])
+    nz = np.nonzero(B[:, 2])[0]
+    assert nz.tolist() == [85]                       # one selected feature at lambda_max
+    pred = r["intercept"] + X[~tr][:, nz] @ B[nz, 2]
+    sse = float(np.sum((y[~tr] - pred) ** 2))
+    assert abs(sse - golden.known["config1"]["cell_alpha1_lambdamax"][0]) < 1e-9
+    assert r["residual"] > 0 and np.all(B[nz, 3] > 0)
+
+
+def test_oracle_probe_counts(golden, oracle):
+    """SURVEY.md probe P2: BASIS 1000 x 481, alpha 0.5, one mid-grid lambda -> M=155, 157 inner
+    iterations, 155 adds with the compiled reference."""
+    X, y = golden.BASIS, golden.y
+    alpha, lam = BuildGrid(X, y, 5)
+    L = np.unique(lam)[::-1]
+    r = oracle.fit_gaussian(X, y, L[12], 0.5)
+    c = r["counters"]
+    assert (c["m_final"], c["n_inner"], c["n_add"]) == (155, 157, 155)
+
+
+def test_oracle_edge_cases(oracle):
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((30, 8))
+    y = X[:, 2] * 2 + rng.standard_normal(30) * 0.1
+    # a zero column gets scale 1 and is never selected; a duplicated column does not break the fit
+    X[:, 5] = 0
+    X[:, 6] = X[:, 2]
+    r = oracle.fit_gaussian(X, y, 0.05, 0.5)
+    assert r["rc"] == 0 and r["Beta"][5, 2] == 0
+    assert np.isfinite(r["intercept"]) and np.isfinite(r["residual"])
+    # huge lambda: nothing can be added, model stays at the initial column
+    r = oracle.fit_gaussian(X, y, 1e6, 1.0)
+    assert r["counters"]["m_final"] == 1 and r["counters"]["n_add"] == 0

@@ -1,0 +1,91 @@
+"""Regenerate tests/golden/ from the reference tree (run in the build container only; the
+reference does not travel to the GPU box, these small fixtures do).
+
+  data fixtures      BASIS / y / BASISbinomial / yBinomial from /root/reference/data/*.rda
+                     (the data files the reference's own example and test use)
+  rds_10000.npz      the stored real-R CrossValidate() output
+                     paper_materials/Real Data Analysis/10000_Features/LooserSubset_10000_ParCV_5-3-2018.RDS
+  config1_gm.npz     oracle output for the reference's own test case (tests/CrossValidate-test.R):
+                     BASIS[1:50,1:100], nFolds=3, 20x20 grid -- 1200 fold SSEs + summary
+  basis481_gm.npz    oracle output for a 15-cell sub-grid of the full bundled data, nFolds=5
+
+Files are read with tools/rdata.py (a pure XDR parser; nothing in the files is executed).
+"""
+import json
+import os
+import sys
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from rdata import read_rda, read_rds, simplify          # noqa: E402
+from pareben_amd.grid import BuildGrid, AssignToFolds, summarise_cv   # noqa: E402
+import oracle_lib as O                                   # noqa: E402
+
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    B = simplify(read_rda(REF + "/data/BASIS.rda")["BASIS"])
+    y = simplify(read_rda(REF + "/data/y.rda")["y"]).reshape(-1)
+    Bb = simplify(read_rda(REF + "/data/BASISbinomial.rda")["BASISbinomial"])
+    yb = simplify(read_rda(REF + "/data/yBinomial.rda")["yBinomial"]).reshape(-1)
+    np.save(OUT + "/BASIS.npy", B.astype(np.int8))
+    np.save(OUT + "/y.npy", y)
+    np.save(OUT + "/BASISbinomial.npy", Bb.astype(np.int8))
+    np.save(OUT + "/yBinomial.npy", yb.astype(np.int8))
+
+    g = simplify(read_rds(REF + "/paper_materials/Real Data Analysis/10000_Features/LooserSubset_10000_ParCV_5-3-2018.RDS"))
+    D, S = g["Results.Detail"], g["Results.Summary"]
+    np.savez_compressed(OUT + "/rds_10000.npz",
+                        detail_foldId=D["foldId"], detail_alpha=D["alpha"], detail_lambda=D["lambda"], detail_MSE=D["MSE"],
+                        summary_alpha=S["alpha"], summary_lambda=S["lambda"], summary_SE=S["SE"], summary_MSE=S["MSE"],
+                        lambda_optimal=g["lambda.optimal"], alpha_optimal=g["alpha.optimal"])
+
+    Bf = B.astype(np.float64)
+    X, yy = Bf[:50, :100], y[:50]
+    fid = AssignToFolds(X, 3)
+    a, l = BuildGrid(X, yy, 3)
+    E, cnt, rc = O.cv_grid(X, yy, fid, 3, a, l)
+    assert rc == 0
+    a_s, l_s, se, err, idx = summarise_cv(a, l, E, 3)
+    np.savez_compressed(OUT + "/config1_gm.npz", alpha=a, lam=l, fold_id=fid, fold_err=E,
+                        summary_alpha=a_s, summary_lambda=l_s, summary_SE=se, summary_MSE=err, idx=idx,
+                        counters=np.array([cnt[k] for k in sorted(cnt)]), counter_names=np.array(sorted(cnt)))
+
+    fid5 = AssignToFolds(Bf, 5)
+    a5, l5 = BuildGrid(Bf, y, 5)
+    A, L = np.unique(a5)[::-1], np.unique(l5)[::-1]
+    sel = [(A[i], L[j]) for i in (0, 9, 19) for j in (0, 5, 10, 14, 19)]
+    aa = np.array([s[0] for s in sel]); ll = np.array([s[1] for s in sel])
+    E5, cnt5, rc = O.cv_grid(Bf, y, fid5, 5, aa, ll)
+    assert rc == 0
+    np.savez_compressed(OUT + "/basis481_gm.npz", alpha=aa, lam=ll, fold_id=fid5, fold_err=E5,
+                        counters=np.array([cnt5[k] for k in sorted(cnt5)]), counter_names=np.array(sorted(cnt5)))
+
+    # numbers recorded in SURVEY.md section 10 (compiled reference C, survey session)
+    known = {
+        "config1": {
+            "folds": "13112123332113311233323312312123221231311121222223",
+            "folds_rounding": "21111232333123331311231131112213222232221322313231",
+            "lambda_first": 2.511584267297302, "lambda_last": 0.002511584267297304,
+            "cell_alpha1_lambdamax": [2246.408042437753, 2004.1589385129005, 1558.6573039729979],
+            "cell_alpha005_lambdamin": [2131.7403270851223, 3156.5655840558547, 3180.85087744276],
+            "alpha_opt": 1.0, "lambda_opt": 0.022249290937151205,
+            "cv_error": 1919.1816087603045, "SE": 180.6896031417665,
+            "nonzero_total": 3682, "max_active": 13,
+        },
+        "rng": {"runif3": [0.2655087, 0.3721239, 0.5728534],
+                "sample10": [9, 4, 7, 1, 2, 5, 3, 10, 6, 8],
+                "sample10_rounding": [3, 4, 5, 7, 2, 8, 9, 6, 10, 1]},
+        "yeast10000": {"lambda_max_x10": 3.156882755270842, "detail_mse_row1": 486.80072139},
+    }
+    with open(OUT + "/survey_known_answers.json", "w") as f:
+        json.dump(known, f, indent=1)
+    print("wrote", sorted(os.listdir(OUT)))
+
+
+if __name__ == "__main__":
+    main()
