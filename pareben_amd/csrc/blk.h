@@ -13,6 +13,7 @@
 
 #ifdef PAREBEN_HOST_EMUL
 #define DEV static inline
+#define DEVNI static
 #define BLK_LANES 1          // lane stride of the 2-d (wave x lane) loops
 struct Blk {
     int tid, nthr, lane, wave, nwave;
@@ -29,6 +30,7 @@ DEV int blk_scan_excl(const Blk &, int v, int *total) { *total = v; return 0; }
 #else
 #include <hip/hip_runtime.h>
 #define DEV __device__ __forceinline__
+#define DEVNI __device__ __noinline__   // big phases: own register allocation, no spill spill-over
 #define BLK_LANES 64
 #define BLK_MAX_WAVES 16
 struct Blk {

@@ -35,7 +35,19 @@
 enum { ACT_NONE = -10, ACT_REEST = 0, ACT_ADD = 1, ACT_DEL = -1, ACT_TERM = 10 };
 enum { UP_FREE = -1, UP_LOST = -2 };
 
+// Optional per-phase tick accumulation (diagnostic build -DPAREBEN_PHASE_TIMERS only; the ticks go
+// to a buffer of their own and never into a result).
+#if defined(PAREBEN_PHASE_TIMERS) && !defined(PAREBEN_HOST_EMUL)
+#define PH_BEGIN() long long ph_t0_ = (B.tid == 0) ? (long long)wall_clock64() : 0
+#define PH_END(k) do { if (B.tid == 0) S.ph[k] += (long long)wall_clock64() - ph_t0_; } while (0)
+#else
+#define PH_BEGIN() do {} while (0)
+#define PH_END(k) do {} while (0)
+#endif
+enum { PH_FS_FEAT = 0, PH_FS_REST = 1, PH_DML = 2, PH_ACTION = 3, PH_NOISE = 4, PH_INVERSE = 5, PH_FINAL_REST = 6, PH_TOTAL = 7 };
+
 struct GmScalars {
+    long long *ph;     // phase ticks (LDS), diagnostic build only
     double beta;       // noise precision
     double b;          // intercept
     int M;             // active-set size
@@ -45,7 +57,7 @@ struct GmScalars {
 #define CNT(stmt) do { if (B.tid == 0) { FitCounters &c = *S.c; stmt; } } while (0)
 
 // S_out/Q_out from S_in/Q_in, MainEff.c:1320-1338 and :664-671
-DEV void gm_refresh_out(const Blk &B, const GmWork &W, int K)
+DEVNI void gm_refresh_out(const Blk &B, const GmWork &W, int K)
 {
     PAR(i, K) {
         double s = W.Sin[i], q = W.Qin[i];
@@ -66,7 +78,7 @@ DEV void gm_refresh_out(const Blk &B, const GmWork &W, int K)
 // b_i = G[used, i].  MainEff.c:1291-1319.  This is the K*M^2 contraction that dominates the
 // run time; lanes run over features (coalesced Gram rows), each wavefront owns
 // 8 rows of Sigma per pass and the Gram tile is staged through LDS once per pass.
-DEV void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W, int K, int M,
+DEVNI void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W, int K, int M,
                               double beta, double *tile, double *xred)
 {
     const int ld = W.ld;
@@ -85,57 +97,98 @@ DEV void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W, i
         W.Qin[i] = beta * (W.bt[i] - bm);
     }
 #else
-    const int NW = B.nwave;
+    // T = Sigma * Bt on the FP64 matrix cores (v_mfma_f64_16x16x4_f64), 16 x 16 tiles of T:
+    // rows j of Sigma x features i.  Wave (g, s) = (wave / 4, wave % 4) owns feature sub-tile s of
+    // the current 64-feature tile and the row tiles g, g + NG, ... (up to FS_JTW per pass), so the
+    // Gram operand (B, from LDS) is reused across its row tiles and the Sigma operand (A, from
+    // L1/L2) across the four waves of a group.  quad_i = sum_j T[j][i] * Bt[j][i] is folded in the
+    // epilogue with two xor-shuffles over the four row groups of the accumulator layout.
+    //   A: lane l holds A[row = l & 15][k = l >> 4];  B: lane l holds B[k = l >> 4][col = l & 15]
+    //   D: register r of lane l is D[row = (l >> 4) + 4 r][col = l & 15]      (f64 layout)
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    constexpr int FS_JTW = 5;          // row tiles per wave and pass
+    constexpr int FS_PC = 32;          // Gram rows staged per chunk
+    constexpr int FS_LD = 80;          // LDS row pitch in doubles (64 + 16: conflict-free b64 reads)
+    const int NW = B.nwave, NG = NW >> 2;
+    const int g = B.wave >> 2, sub = B.wave & 3;
+    const int l15 = B.lane & 15, l4 = B.lane >> 4;
+    const int nJ = (M + 15) >> 4;
+    const int tiles_per_pass = NG * FS_JTW;
+    const int n_pass = (nJ + tiles_per_pass - 1) / tiles_per_pass;
+    const int n_chunk = (M + FS_PC - 1) / FS_PC;
     for (int i0 = 0; i0 < K; i0 += 64) {
-        const int i = i0 + B.lane;
-        const int ic = i < K ? i : K - 1;
-        double quad = 0, bm = 0;
-        for (int j0 = 0; j0 < M; j0 += 8 * NW) {
-            const int jb = j0 + B.wave * 8;
-            double acc[8];
+        const int icol = i0 + sub * 16 + l15;                 // feature of this lane's D column
+        const int icl = icol < K ? icol : K - 1;
+        const int istage = (i0 + B.lane) < K ? (i0 + B.lane) : K - 1;
+        double q_acc = 0, m_acc = 0;
+        for (int pass = 0; pass < n_pass; pass++) {
+            const int jt0 = pass * tiles_per_pass + g;
+            d4 acc[FS_JTW];
 #pragma unroll
-            for (int r = 0; r < 8; r++) acc[r] = 0;
-            for (int p0 = 0; p0 < M; p0 += 64) {
-                const int pc = (M - p0) < 64 ? (M - p0) : 64;
-                __syncthreads();
-                for (int p = B.wave; p < pc; p += NW)
-                    tile[p * 64 + B.lane] = F.G[(size_t)W.used[p0 + p] * K + ic];
-                __syncthreads();
-                if (jb < M) {
-                    const double *srow = W.Sig + (size_t)jb * ld + p0;
-                    if (jb + 8 <= M) {
-                        for (int p = 0; p < pc; p++) {
-                            const double bv = tile[p * 64 + B.lane];
+            for (int t = 0; t < FS_JTW; t++) acc[t] = d4{0, 0, 0, 0};
+            __syncthreads();
+            // stage chunk 0
+            for (int p = B.wave; p < FS_PC; p += NW)
+                tile[p * FS_LD + B.lane] = (p < M) ? F.G[(size_t)W.used[p] * K + istage] : 0.0;
+            __syncthreads();
+            for (int c = 0; c < n_chunk; c++) {
+                const int p0 = c * FS_PC;
+                double *cur = tile + (c & 1) * (FS_PC * FS_LD);
+                double *nxt = tile + ((c + 1) & 1) * (FS_PC * FS_LD);
+                if (c + 1 < n_chunk) {
+                    for (int p = B.wave; p < FS_PC; p += NW) {
+                        const int pp = p0 + FS_PC + p;
+                        nxt[p * FS_LD + B.lane] = (pp < M) ? F.G[(size_t)W.used[pp] * K + istage] : 0.0;
+                    }
+                }
+#pragma unroll 2
+                for (int kk = 0; kk < FS_PC / 4; kk++) {
+                    const int pk = p0 + kk * 4 + l4;                       // k index of this lane
+                    const double bv = cur[(kk * 4 + l4) * FS_LD + sub * 16 + l15];
+                    const double *scol = W.Sig + (size_t)pk * ld;
 #pragma unroll
-                            for (int r = 0; r < 8; r++) acc[r] += srow[(size_t)r * ld + p] * bv;
+                    for (int t = 0; t < FS_JTW; t++) {
+                        const int jt = jt0 + NG * t;
+                        if (jt < nJ) {
+                            const int row = jt * 16 + l15;
+                            const double av = (row < M && pk < M) ? scol[row] : 0.0;
+                            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[t], 0, 0, 0);
                         }
-                    } else {
-                        for (int p = 0; p < pc; p++) {
-                            const double bv = tile[p * 64 + B.lane];
+                    }
+                }
+                __syncthreads();
+            }
 #pragma unroll
-                            for (int r = 0; r < 8; r++)
-                                if (jb + r < M) acc[r] += srow[(size_t)r * ld + p] * bv;
+            for (int t = 0; t < FS_JTW; t++) {
+                const int jt = jt0 + NG * t;
+                if (jt < nJ) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int j = jt * 16 + l4 + 4 * r;
+                        if (j < M) {
+                            const double bj = F.G[(size_t)W.used[j] * K + icl];
+                            q_acc += acc[t][r] * bj;
+                            m_acc += bj * W.mu[j];
                         }
                     }
                 }
             }
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-                const int j = jb + r;
-                if (j < M) {
-                    const double bj = F.G[(size_t)W.used[j] * K + ic];
-                    quad += acc[r] * bj;
-                    bm += bj * W.mu[j];
-                }
-            }
+        }
+        q_acc += __shfl_xor(q_acc, 16, 64); q_acc += __shfl_xor(q_acc, 32, 64);
+        m_acc += __shfl_xor(m_acc, 16, 64); m_acc += __shfl_xor(m_acc, 32, 64);
+        __syncthreads();
+        if (B.lane < 16) {
+            xred[B.wave * 16 + l15] = q_acc;
+            xred[(NW + B.wave) * 16 + l15] = m_acc;
         }
         __syncthreads();
-        xred[B.wave * 64 + B.lane] = quad;
-        xred[(NW + B.wave) * 64 + B.lane] = bm;
-        __syncthreads();
-        if (B.wave == 0 && i < K) {
+        if (B.tid < 64 && i0 + B.tid < K) {
+            const int ss = B.tid >> 4, cc = B.tid & 15, i = i0 + B.tid;
             double q = 0, m = 0;
-            for (int w = 0; w < NW; w++) { q += xred[w * 64 + B.lane]; m += xred[(NW + w) * 64 + B.lane]; }
+            for (int gg = 0; gg < NG; gg++) {
+                q += xred[(gg * 4 + ss) * 16 + cc];
+                m += xred[(NW + gg * 4 + ss) * 16 + cc];
+            }
             W.Sin[i] = beta - beta * q * beta;
             W.Qin[i] = beta * (W.bt[i] - m);
         }
@@ -165,7 +218,7 @@ DEV void gm_fullstat(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmS
         if (i >= 1) W.gam[i] = 1 - W.Sig[(size_t)i * ld + i] * W.A[i];
     }
     blk_sync(B);
-    gm_fullstat_features(B, F, W, K, M, beta, tile, xred);
+    { PH_BEGIN(); gm_fullstat_features(B, F, W, K, M, beta, tile, xred); PH_END(PH_FS_FEAT); }
     gm_refresh_out(B, W, K);
     CNT(c.n_fullstat++; c.sum_m_full += M; c.sum_m2_full += (int64_t)M * M);
 }
@@ -173,7 +226,7 @@ DEV void gm_fullstat(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmS
 // Per-feature marginal-likelihood change and action, MainEff.c:1372-1582.  Returns the arg-max
 // feature and its value.  Ties: lowest index (the reference's first scan visits the active set
 // first; a tie across the two lists needs bit-equal dML of different action types).
-DEV int gm_delta_ml(const Blk &B, const GmWork &W, int K, int N, int M, double lambda, double alpha,
+DEVNI int gm_delta_ml(const Blk &B, const GmWork &W, int K, int N, int M, double lambda, double alpha,
                     double residual, double varY, int iter, int i_iter, int *any_del_out, double *best)
 {
     const double l1 = lambda * alpha, l2 = lambda * (1 - alpha);
@@ -250,7 +303,7 @@ DEV int gm_delta_ml(const Blk &B, const GmWork &W, int K, int N, int M, double l
 }
 
 // ordered list of features with dML >= cutoff (ascending index), MainEff.c:463-473
-DEV int gm_collect(const Blk &B, const GmWork &W, int K, double cutoff)
+DEVNI int gm_collect(const Blk &B, const GmWork &W, int K, double cutoff)
 {
     int base = 0;
     for (int i0 = 0; i0 < K; i0 += B.nthr) {
@@ -267,7 +320,7 @@ DEV int gm_collect(const Blk &B, const GmWork &W, int K, double cutoff)
 
 // a[i] = sum_j G[used[j], i] * vec[j] for all features, fused with the S_in/Q_in update that
 // consumes it.  mode 0: re-estimate (:577-587), 1: add (:1699-1711), 2: delete (:1800-1808).
-DEV void gm_sq_update(const Blk &B, const FoldDev &F, const GmWork &W, int K, int M, const double *vec,
+DEVNI void gm_sq_update(const Blk &B, const FoldDev &F, const GmWork &W, int K, int M, const double *vec,
                       int mode, double beta, double c1, double c2, const double *newrow)
 {
     PAR(i, K) {
@@ -291,7 +344,7 @@ DEV void gm_sq_update(const Blk &B, const FoldDev &F, const GmWork &W, int K, in
 }
 
 // re-estimate slot jj, MainEff.c:553-596
-DEV void gm_reestimate(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScalars &S, int jj, double newA)
+DEVNI void gm_reestimate(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScalars &S, int jj, double newA)
 {
     const int M = S.M, ld = W.ld;
     PAR(i, M) W.v2[i] = W.Sig[(size_t)jj * ld + i];
@@ -311,7 +364,7 @@ DEV void gm_reestimate(const Blk &B, const FoldDev &F, const GmWork &W, int K, G
 }
 
 // add feature nu, MainEff.c:1585-1723 + :613-627
-DEV void gm_add(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScalars &S, int nu, double newA)
+DEVNI void gm_add(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScalars &S, int nu, double newA)
 {
     const int M = S.M, ld = W.ld;
     const double beta = S.beta;
@@ -350,7 +403,7 @@ DEV void gm_add(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScalar
 
 // delete slot jj, MainEff.c:1725-1822 + :640-651.  `nu` is the feature the action named; it
 // differs from used[jj] only on the reference's stale-slot path.
-DEV void gm_delete(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScalars &S, int jj, int nu)
+DEVNI void gm_delete(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScalars &S, int jj, int nu)
 {
     const int M = S.M, ld = W.ld, last = M - 1;
     PAR(i, M) W.v2[i] = W.Sig[(size_t)jj * ld + i];
@@ -393,7 +446,7 @@ DEV void gm_delete(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmSca
 // Sigma <- H^-1 for the SPD M x M matrix held in Sig (in place, Gauss-Jordan without pivoting:
 // the pivots are the Cholesky pivots squared, so a non-positive pivot means "not SPD").
 // Stands in for dpotrf+dpotri (:1346-1369).  Returns 0 on success.
-DEV int gm_spd_inverse(const Blk &B, const GmWork &W, int M)
+DEVNI int gm_spd_inverse(const Blk &B, const GmWork &W, int M)
 {
     const int ld = W.ld;
     for (int k = 0; k < M; k++) {
@@ -418,7 +471,7 @@ DEV int gm_spd_inverse(const Blk &B, const GmWork &W, int M)
 }
 
 // H = beta Phi'Phi + diag(A); Sigma = H^-1; mu = beta Sigma Phi't.  MainEff.c:1841-1921
-DEV int gm_final_update(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScalars &S)
+DEVNI int gm_final_update(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScalars &S)
 {
     const int M = S.M, ld = W.ld;
     const double beta = S.beta;
@@ -435,7 +488,7 @@ DEV int gm_final_update(const Blk &B, const FoldDev &F, const GmWork &W, int K, 
     }
     PAR(l, M) W.v1[l] = W.bt[W.used[l]];
     blk_sync(B);
-    if (gm_spd_inverse(B, W, M)) return 1;
+    { PH_BEGIN(); const int bad = gm_spd_inverse(B, W, M); PH_END(PH_INVERSE); if (bad) return 1; }
     PAR(i, M) {
         double a = 0;
         for (int j = 0; j < M; j++) a += W.v1[j] * W.Sig[(size_t)j * ld + i];
@@ -486,6 +539,7 @@ DEV int gm_inner(const Blk &B, const FoldDev &F, const GmWork &W, int K, double 
         i_iter++;
         CNT(c.n_inner++);
         double best; int any_del;
+        PH_BEGIN();
         int nu = gm_delta_ml(B, W, K, N, S.M, lambda, alpha, residual, varY, iter, i_iter, &any_del, &best);
         int worthwhile;
         if (sel == ACT_TERM && !ini_removed && S.M > 1) nu = -1;
@@ -509,7 +563,9 @@ DEV int gm_inner(const Blk &B, const FoldDev &F, const GmWork &W, int K, double 
             if (n_todo == 0) worthwhile = 0;
         }
         if (!worthwhile) sel = ACT_TERM;
+        PH_END(PH_DML);
         if (worthwhile) {
+            PH_BEGIN();
             for (int u = 0; u < n_todo; u++) {
                 nu = W.todo[u];
                 sel = W.act[nu];
@@ -548,9 +604,11 @@ DEV int gm_inner(const Blk &B, const FoldDev &F, const GmWork &W, int K, double 
                     CNT(if (S.M > c.m_max) c.m_max = S.M);
                 }
             }
+            PH_END(PH_ACTION);
         }
         if (sel == ACT_TERM || i_iter <= 10 || i_iter % 5 == 0 || n_todo >= 2) {   // :685-729
             const int M = S.M;
+            PH_BEGIN();
             double ee_part = 0;
             PAR(h, N) {
                 double pm = 0;
@@ -570,6 +628,7 @@ DEV int gm_inner(const Blk &B, const FoldDev &F, const GmWork &W, int K, double 
             if (nb > 1e6 / varY) nb = 1e6 / varY;
             S.beta = nb;
             const double dlb = log(nb) - log(beta_old);
+            PH_END(PH_NOISE);
             if (fabs(dlb) > 1e-6) {
                 if (gm_final_update(B, F, W, K, S)) { S.status |= ST_CHOLESKY | ST_ABORT; return 1; }
                 if (sel != ACT_TERM) gm_fullstat(B, F, W, K, S, false, tile, xred);

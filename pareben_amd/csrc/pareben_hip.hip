@@ -211,7 +211,9 @@ __device__ inline GmWork ws_carve(char *base, int K, int cap, size_t offK, size_
 // ------------------------------------------------------------------------------------------
 // fit kernels
 
+#ifndef FIT_THREADS
 #define FIT_THREADS 1024
+#endif
 
 struct CvParams {
     const FoldDev *folds;
@@ -221,6 +223,7 @@ struct CvParams {
     double *fold_err;
     int *status;
     long long *counters;              // may be null
+    long long *phase;                 // [n_units x 8] diagnostic ticks, may be null
     char *ws;
     size_t ws_stride, offK, offSig, offM;
     int K, cap, n_folds, n_units;
@@ -246,12 +249,13 @@ __device__ inline void store_counters(long long *dst, const FitCounters &c)
 
 __global__ __launch_bounds__(FIT_THREADS) void gm_cv_kernel(CvParams P)
 {
-    __shared__ double tile[64 * 64];
+    __shared__ double tile[2 * 32 * 80];
     __shared__ double xred[2 * BLK_MAX_WAVES * 64];
     __shared__ double red[2 * BLK_MAX_WAVES];
     __shared__ int ired[2 * BLK_MAX_WAVES];
     __shared__ int s_unit;
     __shared__ FitCounters s_cnt;
+    __shared__ long long s_ph[8];
     const Blk B = make_blk(red, ired);
     const GmWork W = ws_carve(P.ws + (size_t)blockIdx.x * P.ws_stride, P.K, P.cap, P.offK, P.offSig, P.offM);
     for (;;) {
@@ -265,8 +269,20 @@ __global__ __launch_bounds__(FIT_THREADS) void gm_cv_kernel(CvParams P)
         const FoldDev F = P.folds[f];
         GmScalars S;
         S.c = &s_cnt;
+        S.ph = s_ph;
+#ifdef PAREBEN_PHASE_TIMERS
+        if (threadIdx.x < 8) s_ph[threadIdx.x] = 0;
+        __syncthreads();
+        const long long t_fit0 = wall_clock64();
+#endif
         gm_fit(B, F, W, P.K, P.lambda[cell], P.alpha[cell], S, tile, xred);
         const double sse = gm_fold_sse(B, F, W, S);
+#ifdef PAREBEN_PHASE_TIMERS
+        if (threadIdx.x == 0 && P.phase) {
+            s_ph[PH_TOTAL] = wall_clock64() - t_fit0;
+            for (int k = 0; k < 8; k++) P.phase[(size_t)unit * 8 + k] = s_ph[k];
+        }
+#endif
         if (threadIdx.x == 0) {
             P.fold_err[unit] = sse;
             P.status[unit] = S.status;
@@ -290,17 +306,19 @@ struct FitParams {
 // single fit with the reference's .C outputs (elasticNetLinearNeMainEff.c:199-227)
 __global__ __launch_bounds__(FIT_THREADS) void gm_fit_kernel(FitParams P)
 {
-    __shared__ double tile[64 * 64];
+    __shared__ double tile[2 * 32 * 80];
     __shared__ double xred[2 * BLK_MAX_WAVES * 64];
     __shared__ double red[2 * BLK_MAX_WAVES];
     __shared__ int ired[2 * BLK_MAX_WAVES];
     __shared__ FitCounters s_cnt;
+    __shared__ long long s_ph[8];
     const Blk B = make_blk(red, ired);
     const GmWork W = ws_carve(P.ws, P.K, P.cap, P.offK, P.offSig, P.offM);
     const int K = P.K;
     PAR(i, K) { P.Beta[i] = i + 1; P.Beta[K + i] = i + 1; P.Beta[2 * (size_t)K + i] = 0; P.Beta[3 * (size_t)K + i] = 0; }
     GmScalars S;
     S.c = &s_cnt;
+    S.ph = s_ph;
     gm_fit(B, P.F, W, K, P.lambda, P.alpha, S, tile, xred);
     const int M = S.M, ld = W.ld;
     PAR(i, M) {
@@ -507,13 +525,19 @@ extern "C" int pareben_ctx_run(pareben_ctx *c, int n_cells, const double *alpha,
 
     double *d_alpha = nullptr, *d_lambda = nullptr, *d_err = nullptr;
     int *d_order = nullptr, *d_queue = nullptr, *d_status = nullptr;
-    long long *d_cnt = nullptr;
-    auto cleanup = [&]() { hipFree(d_alpha); hipFree(d_lambda); hipFree(d_err); hipFree(d_order); hipFree(d_queue); hipFree(d_status); hipFree(d_cnt); };
+    long long *d_cnt = nullptr, *d_phase = nullptr;
+    const char *phase_path = getenv("PAREBEN_PHASE_DUMP");     // diagnostic build only
+    auto cleanup = [&]() { hipFree(d_phase); hipFree(d_alpha); hipFree(d_lambda); hipFree(d_err); hipFree(d_order); hipFree(d_queue); hipFree(d_status); hipFree(d_cnt); };
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(PAREBEN_EHIP, #x, e_); } } while (0)
     CK(dmalloc(&d_alpha, (size_t)n_cells)); CK(dmalloc(&d_lambda, (size_t)n_cells));
     CK(dmalloc(&d_err, (size_t)n_units)); CK(dmalloc(&d_order, (size_t)n_units));
     CK(dmalloc(&d_queue, (size_t)1)); CK(dmalloc(&d_status, (size_t)n_units));
     if (counters) CK(dmalloc(&d_cnt, (size_t)n_units * PAREBEN_NCOUNTERS));
+#ifdef PAREBEN_PHASE_TIMERS
+    if (phase_path) { CK(dmalloc(&d_phase, (size_t)n_units * 8)); CK(hipMemsetAsync(d_phase, 0, sizeof(long long) * (size_t)n_units * 8, c->stream)); }
+#else
+    (void)phase_path;
+#endif
     CK(hipMemcpyAsync(d_alpha, alpha, sizeof(double) * n_cells, hipMemcpyHostToDevice, c->stream));
     CK(hipMemcpyAsync(d_lambda, lambda, sizeof(double) * n_cells, hipMemcpyHostToDevice, c->stream));
     CK(hipMemcpyAsync(d_order, order.data(), sizeof(int) * n_units, hipMemcpyHostToDevice, c->stream));
@@ -528,7 +552,7 @@ extern "C" int pareben_ctx_run(pareben_ctx *c, int n_cells, const double *alpha,
 
     CvParams P;
     P.folds = c->d_folds; P.alpha = d_alpha; P.lambda = d_lambda; P.order = d_order; P.queue = d_queue;
-    P.fold_err = d_err; P.status = d_status; P.counters = d_cnt; P.ws = c->d_ws;
+    P.fold_err = d_err; P.status = d_status; P.counters = d_cnt; P.phase = d_phase; P.ws = c->d_ws;
     P.ws_stride = c->L.bytes; P.offK = c->L.offK; P.offSig = c->L.offSig; P.offM = c->L.offM;
     P.K = c->p; P.cap = c->cap; P.n_folds = nF; P.n_units = n_units;
     hipLaunchKernelGGL(gm_cv_kernel, dim3(blocks), dim3(FIT_THREADS), 0, c->stream, P);
@@ -542,6 +566,11 @@ extern "C" int pareben_ctx_run(pareben_ctx *c, int n_cells, const double *alpha,
     CK(hipEventRecord(c->ev[3], c->stream));
     CK(hipStreamSynchronize(c->stream));
     if (status) for (int i = 0; i < n_units; i++) status[i] = st[i];
+    if (d_phase) {
+        std::vector<long long> ph((size_t)n_units * 8);
+        CK(hipMemcpy(ph.data(), d_phase, sizeof(long long) * ph.size(), hipMemcpyDeviceToHost));
+        if (FILE *fp = fopen(phase_path, "wb")) { fwrite(ph.data(), sizeof(long long), ph.size(), fp); fclose(fp); }
+    }
     float a = 0, b = 0, t = 0;
     CK(hipEventElapsedTime(&a, c->ev[0], c->ev[1]));
     CK(hipEventElapsedTime(&b, c->ev[1], c->ev[2]));

@@ -100,7 +100,7 @@ extern "C" int emul_gm_cv_grid(const double *basis, int n, int p, const double *
     for (int c = 0; c < n_cells; c++)
         for (int f = 0; f < n_folds; f++) {
             FoldDev F = dev_view(folds[f]);
-            GmScalars S; FitCounters cnt; S.c = &cnt;
+            GmScalars S; FitCounters cnt; S.c = &cnt; S.ph = nullptr;
             gm_fit(B, F, ws.W, p, lambda[c], alpha[c], S, nullptr, nullptr);
             const int u = c * n_folds + f;
             fold_err[u] = gm_fold_sse(B, F, ws.W, S);
@@ -120,7 +120,7 @@ extern "C" int emul_gm_fit(const double *X, const double *y, int n, int p, doubl
     Work ws(p, cap);
     Blk B; B.tid = 0; B.nthr = 1; B.lane = 0; B.wave = 0; B.nwave = 1; B.red = nullptr; B.ired = nullptr;
     FoldDev D = dev_view(F);
-    GmScalars S; FitCounters cnt; S.c = &cnt;
+    GmScalars S; FitCounters cnt; S.c = &cnt; S.ph = nullptr;
     gm_fit(B, D, ws.W, p, lambda, alpha, S, nullptr, nullptr);
     out[0] = S.b; out[1] = S.beta; out[2] = S.M;
     for (int i = 0; i < S.M; i++) { used[i] = ws.W.used[i]; mu[i] = ws.W.mu[i] / F.scale[ws.W.used[i]]; sigdiag[i] = ws.W.Sig[(size_t)i * cap + i] / (F.scale[ws.W.used[i]] * F.scale[ws.W.used[i]]); }

@@ -1,0 +1,37 @@
+"""Diagnostic: per-phase share of the fit kernel's time, from the -DPAREBEN_PHASE_TIMERS build
+(libpareben_hip_prof.so).  Usage: python tools/phase_profile.py [--p 10000 --nlambda 10]"""
+import argparse, os, sys, tempfile
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import pareben_amd._lib as L
+L.LIB_PATH = os.path.join(ROOT, "pareben_amd", "lib", os.environ.get("PAREBEN_PROF_LIB", "libpareben_hip_prof.so"))
+import pareben_amd
+from pareben_amd.grid import BuildGrid, AssignToFolds
+from pareben_amd.synth import synthetic_gaussian
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, default=1000); ap.add_argument("--p", type=int, default=10000)
+ap.add_argument("--nfolds", type=int, default=5); ap.add_argument("--nalpha", type=int, default=20)
+ap.add_argument("--nlambda", type=int, default=10)
+a = ap.parse_args()
+X, y, _, _ = synthetic_gaussian(a.n, a.p)
+alpha, lam = BuildGrid(X, y, a.nfolds, nAlpha=a.nalpha, nLambda=a.nlambda)
+fid = AssignToFolds(X, a.nfolds)
+path = os.path.join(tempfile.gettempdir(), "pareben_phase.bin")
+os.environ["PAREBEN_PHASE_DUMP"] = path
+with pareben_amd.Context(X, y, fid, a.nfolds) as ctx:
+    E, st, cnt = ctx.run(alpha, lam)
+    print("timing", ctx.last_timing(), ctx.launch_info())
+ph = np.fromfile(path, dtype=np.int64).reshape(-1, 8).astype(np.float64)
+names = ["fullstat_features", "fullstat_rest(incl in total only)", "delta_ml+collect", "actions", "noise", "spd_inverse", "final_rest", "total"]
+tot = ph[:, 7].sum()
+print("sum of per-fit wall ticks (100 MHz): %.3f s over %d fits" % (tot / 1e8, len(ph)))
+for k in (0, 2, 3, 4, 5):
+    print("  %-22s %6.2f %%" % (names[k], 100 * ph[:, k].sum() / tot))
+print("  %-22s %6.2f %%" % ("other", 100 * (tot - ph[:, [0, 2, 3, 4, 5]].sum()) / tot))
+heavy = np.argsort(ph[:, 7])[-5:]
+for u in heavy:
+    c = cnt.reshape(-1, 12)[u]
+    print("  fit %d: %.3f s  M=%d inner=%d adds=%d fullstat=%d | " % (u, ph[u, 7] / 1e8, c[9], c[1], c[2], c[5]),
+          " ".join("%s=%.0f%%" % (names[k][:8], 100 * ph[u, k] / ph[u, 7]) for k in (0, 2, 3, 4, 5)))
