@@ -19,6 +19,9 @@ struct Blk {
     int tid, nthr, lane, wave, nwave;
     double *red;     // reduction scratch (unused on the host)
     int *ired;
+    double *pool;    // phase-local LDS pool (device only)
+    double *xred;
+    int pool_n;
 };
 DEV void blk_sync(const Blk &) {}
 DEV double blk_sum(const Blk &, double v) { return v; }
@@ -37,6 +40,9 @@ struct Blk {
     int tid, nthr, lane, wave, nwave;
     double *red;     // LDS: >= 2*BLK_MAX_WAVES doubles
     int *ired;       // LDS: >= 2*BLK_MAX_WAVES ints
+    double *pool;    // LDS: pool_n doubles, owned by whichever phase is running
+    double *xred;    // LDS: 2*BLK_MAX_WAVES*64 doubles
+    int pool_n;
 };
 DEV void blk_sync(const Blk &) { __syncthreads(); }
 

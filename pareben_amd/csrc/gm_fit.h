@@ -74,16 +74,60 @@ DEVNI void gm_refresh_out(const Blk &B, const GmWork &W, int K)
     blk_sync(B);
 }
 
+#ifndef PAREBEN_HOST_EMUL
+// address-space-qualified views (global_load / ds_read instead of flat_load) for the hot loops
+typedef const double __attribute__((address_space(1))) *gptr_cd;
+typedef const int __attribute__((address_space(1))) *gptr_ci;
+typedef double __attribute__((address_space(1))) *gptr_d;
+typedef int __attribute__((address_space(3))) *lptr_i;
+typedef double __attribute__((address_space(3))) *lptr_d;
+typedef double d4 __attribute__((ext_vector_type(4)));
+DEV gptr_cd as_global(const double *p) { return (gptr_cd)p; }
+DEV gptr_ci as_global(const int *p) { return (gptr_ci)p; }
+DEV lptr_d as_lds(double *p) { return (lptr_d)p; }
+DEV lptr_i as_lds(int *p) { return (lptr_i)p; }
+DEV gptr_d as_global_rw(double *p) { return (gptr_d)p; }
+#define FS_JTW 5          // row tiles per wave and pass
+#define FS_PC 32          // Gram rows staged per chunk
+#define FS_LD 80          // LDS row pitch in doubles (64 + 16: conflict-free b64 reads)
+
+// one staged chunk (FS_PC Gram rows = FS_PC/4 k-steps) for NT row tiles; the Sigma operands of
+// k-step kk+1 are loaded while the MFMAs of k-step kk issue.
+template <int NT>
+DEV void fs_chunk(gptr_cd Sig, int ld, int row_max, const size_t *roff, int pk, lptr_d bcol, d4 *acc)
+{
+    double a_cur[NT], a_nxt[NT];
+    {
+        const gptr_cd scol = Sig + (size_t)(pk < row_max ? pk : row_max) * ld;
+#pragma unroll
+        for (int t = 0; t < NT; t++) a_cur[t] = scol[roff[t]];
+    }
+#pragma unroll
+    for (int kk = 0; kk < FS_PC / 4; kk++) {
+        const double bv = bcol[kk * 4 * FS_LD];
+        if (kk + 1 < FS_PC / 4) {
+            const int pn = pk + (kk + 1) * 4;
+            const gptr_cd scol = Sig + (size_t)(pn < row_max ? pn : row_max) * ld;
+#pragma unroll
+            for (int t = 0; t < NT; t++) a_nxt[t] = scol[roff[t]];
+        }
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[t], bv, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; t++) a_cur[t] = a_nxt[t];
+    }
+}
+#endif
+
 // S_in[i] = beta - beta^2 b_i' Sigma b_i,  Q_in[i] = beta (bt_i - b_i' mu)  for every feature,
 // b_i = G[used, i].  MainEff.c:1291-1319.  This is the K*M^2 contraction that dominates the
 // run time; lanes run over features (coalesced Gram rows), each wavefront owns
 // 8 rows of Sigma per pass and the Gram tile is staged through LDS once per pass.
 DEVNI void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W, int K, int M,
-                              double beta, double *tile, double *xred)
+                              double beta)
 {
     const int ld = W.ld;
 #ifdef PAREBEN_HOST_EMUL
-    (void)tile; (void)xred;
     for (int i = 0; i < K; i++) {
         double quad = 0, bm = 0;
         for (int j = 0; j < M; j++) {
@@ -105,10 +149,14 @@ DEVNI void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W,
     // epilogue with two xor-shuffles over the four row groups of the accumulator layout.
     //   A: lane l holds A[row = l & 15][k = l >> 4];  B: lane l holds B[k = l >> 4][col = l & 15]
     //   D: register r of lane l is D[row = (l >> 4) + 4 r][col = l & 15]      (f64 layout)
-    typedef double d4 __attribute__((ext_vector_type(4)));
-    constexpr int FS_JTW = 5;          // row tiles per wave and pass
-    constexpr int FS_PC = 32;          // Gram rows staged per chunk
-    constexpr int FS_LD = 80;          // LDS row pitch in doubles (64 + 16: conflict-free b64 reads)
+    // No masking in the k-loop: Gram rows >= M are staged as zeros, so Sigma entries beyond the
+    // active block (finite: the workspace is zero-initialised) contribute exactly 0; rows >= M of T
+    // are never read back.
+    const gptr_cd Sig = as_global(W.Sig);
+    const gptr_cd G = as_global(F.G);
+    const gptr_ci used = as_global(W.used);
+    const lptr_d lt = as_lds(B.pool);
+    double *xred = B.xred;
     const int NW = B.nwave, NG = NW >> 2;
     const int g = B.wave >> 2, sub = B.wave & 3;
     const int l15 = B.lane & 15, l4 = B.lane >> 4;
@@ -116,6 +164,7 @@ DEVNI void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W,
     const int tiles_per_pass = NG * FS_JTW;
     const int n_pass = (nJ + tiles_per_pass - 1) / tiles_per_pass;
     const int n_chunk = (M + FS_PC - 1) / FS_PC;
+    const int row_max = W.cap - 1;
     for (int i0 = 0; i0 < K; i0 += 64) {
         const int icol = i0 + sub * 16 + l15;                 // feature of this lane's D column
         const int icl = icol < K ? icol : K - 1;
@@ -123,50 +172,53 @@ DEVNI void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W,
         double q_acc = 0, m_acc = 0;
         for (int pass = 0; pass < n_pass; pass++) {
             const int jt0 = pass * tiles_per_pass + g;
+            int nt = (nJ - jt0 + NG - 1) / NG;                // valid row tiles of this wave
+            nt = nt < 0 ? 0 : (nt > FS_JTW ? FS_JTW : nt);
+            nt = __builtin_amdgcn_readfirstlane(nt);          // wave-uniform: scalar branch below
+            size_t roff[FS_JTW];
+#pragma unroll
+            for (int t = 0; t < FS_JTW; t++) {
+                int row = (jt0 + NG * t) * 16 + l15;
+                roff[t] = (size_t)(row < row_max ? row : row_max);
+            }
             d4 acc[FS_JTW];
 #pragma unroll
             for (int t = 0; t < FS_JTW; t++) acc[t] = d4{0, 0, 0, 0};
             __syncthreads();
-            // stage chunk 0
             for (int p = B.wave; p < FS_PC; p += NW)
-                tile[p * FS_LD + B.lane] = (p < M) ? F.G[(size_t)W.used[p] * K + istage] : 0.0;
+                lt[p * FS_LD + B.lane] = (p < M) ? G[(size_t)used[p] * K + istage] : 0.0;
             __syncthreads();
             for (int c = 0; c < n_chunk; c++) {
                 const int p0 = c * FS_PC;
-                double *cur = tile + (c & 1) * (FS_PC * FS_LD);
-                double *nxt = tile + ((c + 1) & 1) * (FS_PC * FS_LD);
+                const lptr_d cur = lt + (c & 1) * (FS_PC * FS_LD);
+                const lptr_d nxt = lt + ((c + 1) & 1) * (FS_PC * FS_LD);
                 if (c + 1 < n_chunk) {
                     for (int p = B.wave; p < FS_PC; p += NW) {
                         const int pp = p0 + FS_PC + p;
-                        nxt[p * FS_LD + B.lane] = (pp < M) ? F.G[(size_t)W.used[pp] * K + istage] : 0.0;
+                        nxt[p * FS_LD + B.lane] = (pp < M) ? G[(size_t)used[pp] * K + istage] : 0.0;
                     }
                 }
-#pragma unroll 2
-                for (int kk = 0; kk < FS_PC / 4; kk++) {
-                    const int pk = p0 + kk * 4 + l4;                       // k index of this lane
-                    const double bv = cur[(kk * 4 + l4) * FS_LD + sub * 16 + l15];
-                    const double *scol = W.Sig + (size_t)pk * ld;
-#pragma unroll
-                    for (int t = 0; t < FS_JTW; t++) {
-                        const int jt = jt0 + NG * t;
-                        if (jt < nJ) {
-                            const int row = jt * 16 + l15;
-                            const double av = (row < M && pk < M) ? scol[row] : 0.0;
-                            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[t], 0, 0, 0);
-                        }
-                    }
+                int pk = p0 + l4;
+                const lptr_d bcol = cur + l4 * FS_LD + sub * 16 + l15;
+                switch (nt) {
+                case 5: fs_chunk<5>(Sig, ld, row_max, roff, pk, bcol, acc); break;
+                case 4: fs_chunk<4>(Sig, ld, row_max, roff, pk, bcol, acc); break;
+                case 3: fs_chunk<3>(Sig, ld, row_max, roff, pk, bcol, acc); break;
+                case 2: fs_chunk<2>(Sig, ld, row_max, roff, pk, bcol, acc); break;
+                case 1: fs_chunk<1>(Sig, ld, row_max, roff, pk, bcol, acc); break;
+                default: break;
                 }
                 __syncthreads();
             }
 #pragma unroll
             for (int t = 0; t < FS_JTW; t++) {
                 const int jt = jt0 + NG * t;
-                if (jt < nJ) {
+                if (t < nt) {
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         const int j = jt * 16 + l4 + 4 * r;
                         if (j < M) {
-                            const double bj = F.G[(size_t)W.used[j] * K + icl];
+                            const double bj = G[(size_t)used[j] * K + icl];
                             q_acc += acc[t][r] * bj;
                             m_acc += bj * W.mu[j];
                         }
@@ -199,7 +251,7 @@ DEVNI void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W,
 
 // Full statistics, MainEff.c:1209-1341 (Q3: gamma[0] is left alone).
 DEV void gm_fullstat(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScalars &S,
-                     bool very_first, double *tile, double *xred)
+                     bool very_first)
 {
     const int M = S.M, ld = W.ld;
     const double beta = S.beta;
@@ -218,7 +270,7 @@ DEV void gm_fullstat(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmS
         if (i >= 1) W.gam[i] = 1 - W.Sig[(size_t)i * ld + i] * W.A[i];
     }
     blk_sync(B);
-    { PH_BEGIN(); gm_fullstat_features(B, F, W, K, M, beta, tile, xred); PH_END(PH_FS_FEAT); }
+    { PH_BEGIN(); gm_fullstat_features(B, F, W, K, M, beta); PH_END(PH_FS_FEAT); }
     gm_refresh_out(B, W, K);
     CNT(c.n_fullstat++; c.sum_m_full += M; c.sum_m2_full += (int64_t)M * M);
 }
@@ -321,11 +373,44 @@ DEVNI int gm_collect(const Blk &B, const GmWork &W, int K, double cutoff)
 // a[i] = sum_j G[used[j], i] * vec[j] for all features, fused with the S_in/Q_in update that
 // consumes it.  mode 0: re-estimate (:577-587), 1: add (:1699-1711), 2: delete (:1800-1808).
 DEVNI void gm_sq_update(const Blk &B, const FoldDev &F, const GmWork &W, int K, int M, const double *vec,
-                      int mode, double beta, double c1, double c2, const double *newrow)
+                        int mode, double beta, double c1, double c2, const double *newrow)
 {
+#ifdef PAREBEN_HOST_EMUL
     PAR(i, K) {
         double a = 0;
         for (int j = 0; j < M; j++) a += F.G[(size_t)W.used[j] * K + i] * vec[j];
+#else
+    // K x M mat-vec over Gram rows: `used`/`vec` staged in LDS, SQ_Q features per thread so that
+    // SQ_Q independent coalesced row loads are in flight per active feature.
+    constexpr int SQ_Q = 5;
+    const gptr_cd G = as_global(F.G);
+    const lptr_d lvec = as_lds(B.pool);
+    const lptr_i lused = as_lds((int *)(B.pool + ((M + 1) & ~1)));
+    blk_sync(B);
+    PAR(j, M) { lvec[j] = vec[j]; lused[j] = W.used[j]; }
+    blk_sync(B);
+    for (int ib = 0; ib < K; ib += SQ_Q * B.nthr) {
+        double accq[SQ_Q];
+        int idx[SQ_Q];
+#pragma unroll
+        for (int q = 0; q < SQ_Q; q++) {
+            accq[q] = 0;
+            const int i = ib + q * B.nthr + B.tid;
+            idx[q] = i < K ? i : K - 1;
+        }
+#pragma unroll 2
+        for (int j = 0; j < M; j++) {
+            const gptr_cd row = G + (size_t)lused[j] * K;
+            const double vj = lvec[j];
+#pragma unroll
+            for (int q = 0; q < SQ_Q; q++) accq[q] += row[idx[q]] * vj;
+        }
+#pragma unroll
+        for (int q = 0; q < SQ_Q; q++) {
+        const int i = ib + q * B.nthr + B.tid;
+        if (i >= K) continue;
+        const double a = accq[q];
+#endif
         if (mode == 0) {                         // c1 = kappa, c2 = mu_jj
             const double ba = beta * a;
             W.Sin[i] = W.Sin[i] + ba * ba * c1;
@@ -339,6 +424,9 @@ DEVNI void gm_sq_update(const Blk &B, const FoldDev &F, const GmWork &W, int K, 
             W.Sin[i] = W.Sin[i] + ba * ba / c1;
             W.Qin[i] = W.Qin[i] + ba * c2 / c1;
         }
+#ifndef PAREBEN_HOST_EMUL
+        }
+#endif
     }
     blk_sync(B);
 }
@@ -446,7 +534,7 @@ DEVNI void gm_delete(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmS
 // Sigma <- H^-1 for the SPD M x M matrix held in Sig (in place, Gauss-Jordan without pivoting:
 // the pivots are the Cholesky pivots squared, so a non-positive pivot means "not SPD").
 // Stands in for dpotrf+dpotri (:1346-1369).  Returns 0 on success.
-DEVNI int gm_spd_inverse(const Blk &B, const GmWork &W, int M)
+DEVNI int gm_spd_inverse_scalar(const Blk &B, const GmWork &W, int M)
 {
     const int ld = W.ld;
     for (int k = 0; k < M; k++) {
@@ -468,6 +556,135 @@ DEVNI int gm_spd_inverse(const Blk &B, const GmWork &W, int M)
         blk_sync(B);
     }
     return 0;
+}
+
+#ifndef PAREBEN_HOST_EMUL
+// Blocked form of the same elimination for the GPU: the symmetric sweep operator applied 16
+// pivots at a time on the lower triangle,
+//     A11 <- -A11^-1,   A21 <- A21 A11^-1,   A22 <- A22 - A21 A11^-1 A21'
+// (after all blocks the matrix holds -H^-1; one last pass negates and mirrors).  The rank-16
+// update of A22 runs on the FP64 matrix cores, one 16 x 16 tile per MFMA group, so the matrix
+// makes M/16 round trips through L2 instead of M.  LDS: Tn = -A21 A11^-1 (M x 16, pitch 18) and
+// the 16 x 16 pivot block.
+#define INV_TP 18
+DEVNI int gm_spd_inverse_blocked(const Blk &B, const GmWork &W, int M)
+{
+    const int ld = W.ld;
+    const gptr_d Sig = as_global_rw(W.Sig);
+    const int nT = (M + 15) >> 4, Mp = nT * 16;
+    const lptr_d Tn = as_lds(B.pool);
+    const lptr_d nD = Tn + (size_t)Mp * INV_TP;              // 16 x 17
+    const int l15 = B.lane & 15, l4 = B.lane >> 4;
+    for (int tk = 0; tk < nT; tk++) {
+        const int k0 = tk * 16;
+        __syncthreads();
+        if (B.tid < 256) {                                   // pivot block (identity-padded)
+            const int r = B.tid & 15, c = B.tid >> 4, gi = k0 + r, gj = k0 + c;
+            double v;
+            if (gi < M && gj < M) { const int hi = gi > gj ? gi : gj, lo = gi > gj ? gj : gi; v = Sig[(size_t)lo * ld + hi]; }
+            else v = (gi == gj) ? 1.0 : 0.0;
+            nD[r * 17 + c] = v;
+        }
+        __syncthreads();
+        for (int s = 0; s < 16; s++) {                        // scalar sweeps inside the block
+            const double d = nD[s * 17 + s];
+            if (!(d > 0)) return 1;
+            double nv = 0;
+            if (B.tid < 256) {
+                const int r = B.tid & 15, c = B.tid >> 4;
+                const double prs = nD[r * 17 + s], psc = nD[s * 17 + c], v = nD[r * 17 + c];
+                if (r == s && c == s) nv = -1.0 / d;
+                else if (r == s) nv = psc / d;
+                else if (c == s) nv = prs / d;
+                else nv = v - prs * psc / d;
+            }
+            __syncthreads();
+            if (B.tid < 256) nD[(B.tid & 15) * 17 + (B.tid >> 4)] = nv;
+            __syncthreads();
+        }
+        // Tn[i][r] = sum_s A(i, k0+s) * nD[s][r] for rows outside the block (zero inside / padding)
+        for (int i = B.tid; i < Mp; i += B.nthr) {
+            double lp[16];
+            const bool live = i < M && (i < k0 || i >= k0 + 16);
+#pragma unroll
+            for (int s2 = 0; s2 < 16; s2++) {
+                const int kc = k0 + s2;
+                double v = 0;
+                if (live && kc < M) v = (i > kc) ? Sig[(size_t)kc * ld + i] : Sig[(size_t)i * ld + kc];
+                lp[s2] = v;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                double t = 0;
+#pragma unroll
+                for (int s2 = 0; s2 < 16; s2++) t += lp[s2] * nD[s2 * 17 + r];
+                Tn[(size_t)i * INV_TP + r] = t;
+            }
+        }
+        __syncthreads();
+        // A22 += Tn * A21'  on the lower-triangle tiles that do not touch the pivot block.
+        // MFMA rows <-> j (column of A), MFMA columns <-> i (row of A): stores are contiguous in i.
+        int q = 0;
+        for (int ti = 0; ti < nT; ti++) {
+            if (ti == tk) continue;
+            for (int tj = 0; tj <= ti; tj++) {
+                if (tj == tk) continue;
+                if ((q++ % B.nwave) != B.wave) continue;
+                const int jrow = tj * 16 + l15;               // A-operand row  (column j of the matrix)
+                const int icol = ti * 16 + l15;               // B-operand / D column (row i of the matrix)
+                d4 acc;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int j = tj * 16 + l4 + 4 * r;
+                    acc[r] = (icol < M && j < M) ? Sig[(size_t)j * ld + icol] : 0.0;
+                }
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) {
+                    const int kc = k0 + kk * 4 + l4;
+                    double av = 0;
+                    if (jrow < M && kc < M) av = (jrow > kc) ? Sig[(size_t)kc * ld + jrow] : Sig[(size_t)jrow * ld + kc];
+                    const double bv = Tn[(size_t)icol * INV_TP + kk * 4 + l4];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int j = tj * 16 + l4 + 4 * r;
+                    if (icol < M && j < M) Sig[(size_t)j * ld + icol] = acc[r];
+                }
+            }
+        }
+        __syncthreads();
+        // pivot column panel <- A21 A11^-1 = -Tn, pivot block <- -A11^-1
+        for (int e = B.tid; e < Mp * 16; e += B.nthr) {
+            const int i = e >> 4, r = e & 15, kc = k0 + r;
+            if (i >= M || kc >= M || (i >= k0 && i < k0 + 16)) continue;
+            const double v = -Tn[(size_t)i * INV_TP + r];
+            if (i > kc) Sig[(size_t)kc * ld + i] = v; else Sig[(size_t)i * ld + kc] = v;
+        }
+        if (B.tid < 256) {
+            const int r = B.tid & 15, c = B.tid >> 4;
+            if (k0 + r < M && k0 + c < M) Sig[(size_t)(k0 + c) * ld + k0 + r] = nD[r * 17 + c];
+        }
+    }
+    __syncthreads();
+    for (int j = B.wave; j < M; j += B.nwave)
+        for (int i = j + B.lane; i < M; i += 64) {
+            const double v = -Sig[(size_t)j * ld + i];
+            Sig[(size_t)j * ld + i] = v;
+            Sig[(size_t)i * ld + j] = v;
+        }
+    __syncthreads();
+    return 0;
+}
+#endif
+
+DEV int gm_spd_inverse(const Blk &B, const GmWork &W, int M)
+{
+#ifndef PAREBEN_HOST_EMUL
+    const int Mp = ((M + 15) >> 4) * 16;
+    if (M > 16 && Mp * INV_TP + 16 * 17 <= B.pool_n) return gm_spd_inverse_blocked(B, W, M);
+#endif
+    return gm_spd_inverse_scalar(B, W, M);
 }
 
 // H = beta Phi'Phi + diag(A); Sigma = H^-1; mu = beta Sigma Phi't.  MainEff.c:1841-1921
@@ -502,8 +719,7 @@ DEVNI int gm_final_update(const Blk &B, const FoldDev &F, const GmWork &W, int K
 // *cs = sum_i Csum_i and *csy = Csum.y with Csum the column sums of
 // C^-1 = beta I - beta^2 Phi Sigma Phi' (:741-781, :172-187), formed in O(N M + M^2).
 DEV int gm_inner(const Blk &B, const FoldDev &F, const GmWork &W, int K, double lambda, double alpha,
-                 GmScalars &S, int iter, double residual, double varY, double *cs, double *csy,
-                 double *tile, double *xred)
+                 GmScalars &S, int iter, double residual, double varY, double *cs, double *csy)
 {
     const int N = F.N, ld = W.ld;
     const bool first = iter <= 1;
@@ -531,7 +747,7 @@ DEV int gm_inner(const Blk &B, const FoldDev &F, const GmWork &W, int K, double 
     const int initial = W.used[0];
     int ini_removed = first ? 0 : 1;
     int i_iter = 0;
-    gm_fullstat(B, F, W, K, S, iter == 1, tile, xred);
+    gm_fullstat(B, F, W, K, S, iter == 1);
 
     int sel = ACT_NONE, jj = -1, n_todo = 0, last_it = 0;
     const int it_max = iter == 1 ? 10 : 100;
@@ -631,7 +847,7 @@ DEV int gm_inner(const Blk &B, const FoldDev &F, const GmWork &W, int K, double 
             PH_END(PH_NOISE);
             if (fabs(dlb) > 1e-6) {
                 if (gm_final_update(B, F, W, K, S)) { S.status |= ST_CHOLESKY | ST_ABORT; return 1; }
-                if (sel != ACT_TERM) gm_fullstat(B, F, W, K, S, false, tile, xred);
+                if (sel != ACT_TERM) gm_fullstat(B, F, W, K, S, false);
             }
         }
         GM_TRACE("  it %d.%d M=%d sel=%d ntodo=%d beta=%.15g mu0=%.15g A0=%.15g gam0=%.15g\n", iter, i_iter, S.M, sel, n_todo, S.beta, W.mu[0], W.A[0], W.gam[0]);
@@ -670,7 +886,7 @@ DEV int gm_inner(const Blk &B, const FoldDev &F, const GmWork &W, int K, double 
 // The whole fit: MainEff.c:55-242.  On return S.b = intercept, S.beta = noise precision,
 // W.used/W.mu/W.Sig hold the model (mu in normalised-column units).
 DEV void gm_fit(const Blk &B, const FoldDev &F, const GmWork &W, int K, double lambda, double alpha,
-                GmScalars &S, double *tile, double *xred)
+                GmScalars &S)
 {
     S.b = F.ymean;
     S.status = 0;
@@ -683,7 +899,7 @@ DEV void gm_fit(const Blk &B, const FoldDev &F, const GmWork &W, int K, double l
         iter++;
         vk0 = vk;
         double cs, csy;
-        if (gm_inner(B, F, W, K, lambda, alpha, S, iter, residvar, varT, &cs, &csy, tile, xred)) break;
+        if (gm_inner(B, F, W, K, lambda, alpha, S, iter, residvar, varT, &cs, &csy)) break;
         S.b = csy / (cs + 1e-10);
         double a_part = 0;
         PAR(i, S.M) a_part += W.A[i];

@@ -229,14 +229,24 @@ struct CvParams {
     int K, cap, n_folds, n_units;
 };
 
-__device__ inline Blk make_blk(double *red, int *ired)
+// LDS carve of one fit workgroup (dynamic shared memory): a phase-local pool (full-stat Gram
+// tiles / inverse panels / action vectors), the cross-wave reduction slab and the small scratch.
+#define LDS_POOL_DOUBLES 16384
+#define LDS_XRED_DOUBLES (2 * BLK_MAX_WAVES * 64)
+#define LDS_FIT_BYTES ((LDS_POOL_DOUBLES + LDS_XRED_DOUBLES + 2 * BLK_MAX_WAVES) * 8 + 2 * BLK_MAX_WAVES * 4)
+extern __shared__ double lds_dyn[];
+
+__device__ inline Blk make_blk()
 {
     Blk B;
     B.tid = threadIdx.x; B.nthr = blockDim.x;
     B.lane = threadIdx.x & 63;
     B.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     B.nwave = blockDim.x >> 6;
-    B.red = red; B.ired = ired;
+    B.pool = lds_dyn; B.pool_n = LDS_POOL_DOUBLES;
+    B.xred = lds_dyn + LDS_POOL_DOUBLES;
+    B.red = B.xred + LDS_XRED_DOUBLES;
+    B.ired = (int *)(B.red + 2 * BLK_MAX_WAVES);
     return B;
 }
 
@@ -249,14 +259,10 @@ __device__ inline void store_counters(long long *dst, const FitCounters &c)
 
 __global__ __launch_bounds__(FIT_THREADS) void gm_cv_kernel(CvParams P)
 {
-    __shared__ double tile[2 * 32 * 80];
-    __shared__ double xred[2 * BLK_MAX_WAVES * 64];
-    __shared__ double red[2 * BLK_MAX_WAVES];
-    __shared__ int ired[2 * BLK_MAX_WAVES];
     __shared__ int s_unit;
     __shared__ FitCounters s_cnt;
     __shared__ long long s_ph[8];
-    const Blk B = make_blk(red, ired);
+    const Blk B = make_blk();
     const GmWork W = ws_carve(P.ws + (size_t)blockIdx.x * P.ws_stride, P.K, P.cap, P.offK, P.offSig, P.offM);
     for (;;) {
         __syncthreads();
@@ -275,7 +281,7 @@ __global__ __launch_bounds__(FIT_THREADS) void gm_cv_kernel(CvParams P)
         __syncthreads();
         const long long t_fit0 = wall_clock64();
 #endif
-        gm_fit(B, F, W, P.K, P.lambda[cell], P.alpha[cell], S, tile, xred);
+        gm_fit(B, F, W, P.K, P.lambda[cell], P.alpha[cell], S);
         const double sse = gm_fold_sse(B, F, W, S);
 #ifdef PAREBEN_PHASE_TIMERS
         if (threadIdx.x == 0 && P.phase) {
@@ -306,20 +312,16 @@ struct FitParams {
 // single fit with the reference's .C outputs (elasticNetLinearNeMainEff.c:199-227)
 __global__ __launch_bounds__(FIT_THREADS) void gm_fit_kernel(FitParams P)
 {
-    __shared__ double tile[2 * 32 * 80];
-    __shared__ double xred[2 * BLK_MAX_WAVES * 64];
-    __shared__ double red[2 * BLK_MAX_WAVES];
-    __shared__ int ired[2 * BLK_MAX_WAVES];
     __shared__ FitCounters s_cnt;
     __shared__ long long s_ph[8];
-    const Blk B = make_blk(red, ired);
+    const Blk B = make_blk();
     const GmWork W = ws_carve(P.ws, P.K, P.cap, P.offK, P.offSig, P.offM);
     const int K = P.K;
     PAR(i, K) { P.Beta[i] = i + 1; P.Beta[K + i] = i + 1; P.Beta[2 * (size_t)K + i] = 0; P.Beta[3 * (size_t)K + i] = 0; }
     GmScalars S;
     S.c = &s_cnt;
     S.ph = s_ph;
-    gm_fit(B, P.F, W, K, P.lambda, P.alpha, S, tile, xred);
+    gm_fit(B, P.F, W, K, P.lambda, P.alpha, S);
     const int M = S.M, ld = W.ld;
     PAR(i, M) {
         const int f = W.used[i];
@@ -494,6 +496,10 @@ static int ensure_workspace(pareben_ctx *c, int blocks)
         if (c->d_ws) { hipFree(c->d_ws); c->d_ws = nullptr; c->ws_bytes = 0; }
         hipError_t e = hipMalloc((void **)&c->d_ws, need);
         if (e != hipSuccess) return fail(PAREBEN_ENOMEM, "workspace hipMalloc", e);
+        // zero once: the matrix-core full-stat pass reads (and multiplies by exact zeros) Sigma
+        // entries just outside the active block, which must therefore be finite
+        e = hipMemset(c->d_ws, 0, need);
+        if (e != hipSuccess) return fail(PAREBEN_EHIP, "workspace hipMemset", e);
         c->ws_bytes = need;
     }
     c->ws_blocks = blocks;
@@ -517,7 +523,8 @@ extern "C" int pareben_ctx_run(pareben_ctx *c, int n_cells, const double *alpha,
     for (int k = 0; k < n_cells; k++) for (int f = 0; f < nF; f++) order[k * nF + f] = cells[k] * nF + f;
 
     int occ = 1;
-    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, gm_cv_kernel, FIT_THREADS, 0));
+    HIPCHK(hipFuncSetAttribute((const void *)gm_cv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FIT_BYTES));
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, gm_cv_kernel, FIT_THREADS, LDS_FIT_BYTES));
     if (occ < 1) occ = 1;
     int blocks = std::min(n_units, c->n_cu * occ);
     int rc = ensure_workspace(c, blocks);
@@ -555,7 +562,7 @@ extern "C" int pareben_ctx_run(pareben_ctx *c, int n_cells, const double *alpha,
     P.fold_err = d_err; P.status = d_status; P.counters = d_cnt; P.phase = d_phase; P.ws = c->d_ws;
     P.ws_stride = c->L.bytes; P.offK = c->L.offK; P.offSig = c->L.offSig; P.offM = c->L.offM;
     P.K = c->p; P.cap = c->cap; P.n_folds = nF; P.n_units = n_units;
-    hipLaunchKernelGGL(gm_cv_kernel, dim3(blocks), dim3(FIT_THREADS), 0, c->stream, P);
+    hipLaunchKernelGGL(gm_cv_kernel, dim3(blocks), dim3(FIT_THREADS), LDS_FIT_BYTES, c->stream, P);
     CK(hipGetLastError());
     CK(hipEventRecord(c->ev[2], c->stream));
 
@@ -639,7 +646,8 @@ extern "C" int pareben_fit_gaussian(const double *basis, const double *target, d
     CK(hipMemcpy(&P.F, c->d_folds, sizeof(FoldDev), hipMemcpyDeviceToHost));
     P.lambda = lambda; P.alpha = alpha; P.Beta = d_beta; P.scalars = d_sc; P.status = d_st; P.counters = d_cnt;
     P.ws = c->d_ws; P.offK = c->L.offK; P.offSig = c->L.offSig; P.offM = c->L.offM; P.K = k; P.cap = c->cap;
-    hipLaunchKernelGGL(gm_fit_kernel, dim3(1), dim3(FIT_THREADS), 0, c->stream, P);
+    CK(hipFuncSetAttribute((const void *)gm_fit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FIT_BYTES));
+    hipLaunchKernelGGL(gm_fit_kernel, dim3(1), dim3(FIT_THREADS), LDS_FIT_BYTES, c->stream, P);
     CK(hipGetLastError());
     CK(hipStreamSynchronize(c->stream));
     double sc[3]; int st = 0;

@@ -96,12 +96,12 @@ extern "C" int emul_gm_cv_grid(const double *basis, int n, int p, const double *
     std::vector<Fold> folds(n_folds);
     for (int f = 0; f < n_folds; f++) prepare(folds[f], basis, n, p, y, fold_id, f);
     Work ws(p, cap);
-    Blk B; B.tid = 0; B.nthr = 1; B.lane = 0; B.wave = 0; B.nwave = 1; B.red = nullptr; B.ired = nullptr;
+    Blk B; B.tid = 0; B.nthr = 1; B.lane = 0; B.wave = 0; B.nwave = 1; B.red = nullptr; B.ired = nullptr; B.pool = nullptr; B.xred = nullptr; B.pool_n = 0;
     for (int c = 0; c < n_cells; c++)
         for (int f = 0; f < n_folds; f++) {
             FoldDev F = dev_view(folds[f]);
             GmScalars S; FitCounters cnt; S.c = &cnt; S.ph = nullptr;
-            gm_fit(B, F, ws.W, p, lambda[c], alpha[c], S, nullptr, nullptr);
+            gm_fit(B, F, ws.W, p, lambda[c], alpha[c], S);
             const int u = c * n_folds + f;
             fold_err[u] = gm_fold_sse(B, F, ws.W, S);
             if (status) status[u] = S.status;
@@ -118,10 +118,10 @@ extern "C" int emul_gm_fit(const double *X, const double *y, int n, int p, doubl
     Fold F; prepare(F, X, n, p, y, fid.data(), 0);
     const int cap = emul_default_cap(p);
     Work ws(p, cap);
-    Blk B; B.tid = 0; B.nthr = 1; B.lane = 0; B.wave = 0; B.nwave = 1; B.red = nullptr; B.ired = nullptr;
+    Blk B; B.tid = 0; B.nthr = 1; B.lane = 0; B.wave = 0; B.nwave = 1; B.red = nullptr; B.ired = nullptr; B.pool = nullptr; B.xred = nullptr; B.pool_n = 0;
     FoldDev D = dev_view(F);
     GmScalars S; FitCounters cnt; S.c = &cnt; S.ph = nullptr;
-    gm_fit(B, D, ws.W, p, lambda, alpha, S, nullptr, nullptr);
+    gm_fit(B, D, ws.W, p, lambda, alpha, S);
     out[0] = S.b; out[1] = S.beta; out[2] = S.M;
     for (int i = 0; i < S.M; i++) { used[i] = ws.W.used[i]; mu[i] = ws.W.mu[i] / F.scale[ws.W.used[i]]; sigdiag[i] = ws.W.Sig[(size_t)i * cap + i] / (F.scale[ws.W.used[i]] * F.scale[ws.W.used[i]]); }
     if (counters) std::memcpy(counters, &cnt, sizeof cnt);
