@@ -87,34 +87,91 @@ DEV gptr_ci as_global(const int *p) { return (gptr_ci)p; }
 DEV lptr_d as_lds(double *p) { return (lptr_d)p; }
 DEV lptr_i as_lds(int *p) { return (lptr_i)p; }
 DEV gptr_d as_global_rw(double *p) { return (gptr_d)p; }
-#define FS_JTW 5          // row tiles per wave and pass
+// Arguments of non-inlined device functions arrive in VGPRs; these put wave-uniform values back
+// into SGPRs so addresses become "scalar base + 32-bit lane offset" (fewer VGPRs, saddr loads).
+DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <class T> DEV T *uni_ptr(T *p)
+{
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (T *)(((unsigned long long)hi << 32) | lo);
+}
+#define FS_JTW 2          // row tiles per wave and pass (each against 4 feature sub-tiles)
 #define FS_PC 32          // Gram rows staged per chunk
 #define FS_LD 80          // LDS row pitch in doubles (64 + 16: conflict-free b64 reads)
+#define FS_SR 4           // staged rows per wave and chunk (FS_PC / 8 waves at least)
+#define FS_PF 4           // Sigma-operand prefetch distance in k-steps (divides FS_PC / 4)
 
-// one staged chunk (FS_PC Gram rows = FS_PC/4 k-steps) for NT row tiles; the Sigma operands of
-// k-step kk+1 are loaded while the MFMAs of k-step kk issue.
+// All k-steps of one pass for the NT (<= 2) row tiles of this wave against the four 16-feature
+// sub-tiles of the staged Gram tile: per k-step NT Sigma-operand loads feed 4*NT MFMAs.
+//   * Sigma lives beyond L2 (every workgroup owns a different one): its operands are prefetched
+//     FS_PF k-steps ahead through a register ring that runs across the LDS chunk boundaries.
+//   * Sigma is symmetric: row tile J only visits the k-blocks P <= J; the strictly-lower blocks
+//     count twice (acc *= 2 when the diagonal block is reached), which halves the matrix work.
+//   * the Gram rows of chunk c+1 are fetched into registers at the start of chunk c and written
+//     to LDS after its MFMAs.
 template <int NT>
-DEV void fs_chunk(gptr_cd Sig, int ld, int row_max, const size_t *roff, int pk, lptr_d bcol, d4 *acc)
+DEV void fs_pass(gptr_cd Sig, gptr_cd G, lptr_i lused, lptr_d lt, int ld, int row_max, const int *roff,
+                 int M, int K, int n_chunk, int istage, int wave, int lane, int NW, const int *kdiag,
+                 d4 (*acc)[4])
 {
-    double a_cur[NT], a_nxt[NT];
-    {
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int nk = n_chunk * (FS_PC / 4);
+    double a[FS_PF][NT];
+#pragma unroll
+    for (int s = 0; s < FS_PF; s++) {
+        const int pk = s * 4 + l4;
         const gptr_cd scol = Sig + (size_t)(pk < row_max ? pk : row_max) * ld;
 #pragma unroll
-        for (int t = 0; t < NT; t++) a_cur[t] = scol[roff[t]];
+        for (int t = 0; t < NT; t++) if (s < kdiag[t] + 4) a[s][t] = scol[roff[t]];
     }
+    double st[FS_SR];
+    for (int kk0 = 0; kk0 < nk; kk0 += FS_PF) {
 #pragma unroll
-    for (int kk = 0; kk < FS_PC / 4; kk++) {
-        const double bv = bcol[kk * 4 * FS_LD];
-        if (kk + 1 < FS_PC / 4) {
-            const int pn = pk + (kk + 1) * 4;
-            const gptr_cd scol = Sig + (size_t)(pn < row_max ? pn : row_max) * ld;
+        for (int s = 0; s < FS_PF; s++) {
+            const int kk = kk0 + s;
+            const int c = kk / (FS_PC / 4), kin = kk % (FS_PC / 4);
+            const lptr_d cur = lt + (c & 1) * (FS_PC * FS_LD);
+            if (kin == 0 && c + 1 < n_chunk) {
 #pragma unroll
-            for (int t = 0; t < NT; t++) a_nxt[t] = scol[roff[t]];
+                for (int r = 0; r < FS_SR; r++) {
+                    const int p = wave + r * NW, pp = (c + 1) * FS_PC + p;
+                    st[r] = (p < FS_PC && pp < M) ? G[(size_t)lused[pp] * K + istage] : 0.0;
+                }
+            }
+            double bv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) bv[u] = cur[(kin * 4 + l4) * FS_LD + u * 16 + l15];
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                if (kk < kdiag[t] + 4) {
+                    if (kk == kdiag[t]) {
+#pragma unroll
+                        for (int u = 0; u < 4; u++) acc[t][u] = acc[t][u] * 2.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        acc[t][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s][t], bv[u], acc[t][u], 0, 0, 0);
+                }
+            }
+            if (kk + FS_PF < nk) {
+                const int pk = (kk + FS_PF) * 4 + l4;
+                const gptr_cd scol = Sig + (size_t)(pk < row_max ? pk : row_max) * ld;
+#pragma unroll
+                for (int t = 0; t < NT; t++) if (kk + FS_PF < kdiag[t] + 4) a[s][t] = scol[roff[t]];
+            }
+            if (kin == FS_PC / 4 - 1) {
+                if (c + 1 < n_chunk) {
+                    const lptr_d nxt = lt + ((c + 1) & 1) * (FS_PC * FS_LD);
+#pragma unroll
+                    for (int r = 0; r < FS_SR; r++) {
+                        const int p = wave + r * NW;
+                        if (p < FS_PC) nxt[p * FS_LD + lane] = st[r];
+                    }
+                }
+                __syncthreads();
+            }
         }
-#pragma unroll
-        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[t], bv, acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < NT; t++) a_cur[t] = a_nxt[t];
     }
 }
 #endif
@@ -126,8 +183,8 @@ DEV void fs_chunk(gptr_cd Sig, int ld, int row_max, const size_t *roff, int pk, 
 DEVNI void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W, int K, int M,
                               double beta)
 {
-    const int ld = W.ld;
 #ifdef PAREBEN_HOST_EMUL
+    const int ld = W.ld;
     for (int i = 0; i < K; i++) {
         double quad = 0, bm = 0;
         for (int j = 0; j < M; j++) {
@@ -142,105 +199,118 @@ DEVNI void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W,
     }
 #else
     // T = Sigma * Bt on the FP64 matrix cores (v_mfma_f64_16x16x4_f64), 16 x 16 tiles of T:
-    // rows j of Sigma x features i.  Wave (g, s) = (wave / 4, wave % 4) owns feature sub-tile s of
-    // the current 64-feature tile and the row tiles g, g + NG, ... (up to FS_JTW per pass), so the
-    // Gram operand (B, from LDS) is reused across its row tiles and the Sigma operand (A, from
-    // L1/L2) across the four waves of a group.  quad_i = sum_j T[j][i] * Bt[j][i] is folded in the
-    // epilogue with two xor-shuffles over the four row groups of the accumulator layout.
+    // rows j of Sigma x features i.  A 64-feature Gram tile is staged through LDS in 32-row chunks;
+    // every wave owns up to two 16-row tiles of Sigma per pass (w and 2 NW - 1 - w: with the
+    // triangular, symmetric schedule both halves cost the same) and multiplies them against all
+    // four 16-feature sub-tiles.  quad_i = sum_j T[j][i] * Bt[j][i] is folded in the epilogue with
+    // two xor-shuffles over the four row groups of the accumulator layout.
     //   A: lane l holds A[row = l & 15][k = l >> 4];  B: lane l holds B[k = l >> 4][col = l & 15]
     //   D: register r of lane l is D[row = (l >> 4) + 4 r][col = l & 15]      (f64 layout)
     // No masking in the k-loop: Gram rows >= M are staged as zeros, so Sigma entries beyond the
     // active block (finite: the workspace is zero-initialised) contribute exactly 0; rows >= M of T
     // are never read back.
-    const gptr_cd Sig = as_global(W.Sig);
-    const gptr_cd G = as_global(F.G);
-    const gptr_ci used = as_global(W.used);
-    const lptr_d lt = as_lds(B.pool);
-    double *xred = B.xred;
-    const int NW = B.nwave, NG = NW >> 2;
-    const int g = B.wave >> 2, sub = B.wave & 3;
+    const gptr_cd Sig = as_global(uni_ptr(W.Sig));
+    const gptr_cd G = as_global(uni_ptr(F.G));
+    double *pool = uni_ptr(B.pool);
+    const lptr_d lt = as_lds(pool);
+    const lptr_i lused = as_lds((int *)(pool + 2 * FS_PC * FS_LD));   // active-set ids, M <= 2048
+    double *xred = uni_ptr(B.xred);
+    K = uni(K); M = uni(M);
+    const int ld = uni(W.ld);
+    __syncthreads();
+    for (int p = B.tid; p < M; p += B.nthr) lused[p] = W.used[p];
+    __syncthreads();
+    const int NW = uni(B.nwave);
     const int l15 = B.lane & 15, l4 = B.lane >> 4;
     const int nJ = (M + 15) >> 4;
-    const int tiles_per_pass = NG * FS_JTW;
+    const int tiles_per_pass = NW * FS_JTW;
     const int n_pass = (nJ + tiles_per_pass - 1) / tiles_per_pass;
-    const int n_chunk = (M + FS_PC - 1) / FS_PC;
-    const int row_max = W.cap - 1;
+    const int row_max = uni(W.cap) - 1;
     for (int i0 = 0; i0 < K; i0 += 64) {
-        const int icol = i0 + sub * 16 + l15;                 // feature of this lane's D column
-        const int icl = icol < K ? icol : K - 1;
         const int istage = (i0 + B.lane) < K ? (i0 + B.lane) : K - 1;
-        double q_acc = 0, m_acc = 0;
+        double q_acc[4], m_acc[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { q_acc[u] = 0; m_acc[u] = 0; }
         for (int pass = 0; pass < n_pass; pass++) {
-            const int jt0 = pass * tiles_per_pass + g;
-            int nt = (nJ - jt0 + NG - 1) / NG;                // valid row tiles of this wave
-            nt = nt < 0 ? 0 : (nt > FS_JTW ? FS_JTW : nt);
-            nt = __builtin_amdgcn_readfirstlane(nt);          // wave-uniform: scalar branch below
-            size_t roff[FS_JTW];
+            const int jbase = pass * tiles_per_pass;
+            int jts[FS_JTW], roff[FS_JTW], kdiag[FS_JTW];
+            jts[0] = jbase + B.wave;                          // w and 2 NW - 1 - w: with the triangular
+            jts[1] = jbase + 2 * NW - 1 - B.wave;             // schedule both halves cost the same
+            int nt = 0;
 #pragma unroll
             for (int t = 0; t < FS_JTW; t++) {
-                int row = (jt0 + NG * t) * 16 + l15;
-                roff[t] = (size_t)(row < row_max ? row : row_max);
+                if (jts[t] < nJ) nt = t + 1;
+                const int row = jts[t] * 16 + l15;
+                roff[t] = row < row_max ? row : row_max;
+                kdiag[t] = __builtin_amdgcn_readfirstlane(jts[t] < nJ ? jts[t] * 4 : -8);
             }
-            d4 acc[FS_JTW];
+            nt = __builtin_amdgcn_readfirstlane(nt);
+            const int last_tile = (jbase + tiles_per_pass < nJ ? jbase + tiles_per_pass : nJ) - 1;
+            const int n_chunk = (last_tile * 16 + 16 + FS_PC - 1) / FS_PC;    // k-blocks this pass needs
+            d4 acc[FS_JTW][4];
 #pragma unroll
-            for (int t = 0; t < FS_JTW; t++) acc[t] = d4{0, 0, 0, 0};
+            for (int t = 0; t < FS_JTW; t++)
+#pragma unroll
+                for (int u = 0; u < 4; u++) acc[t][u] = d4{0, 0, 0, 0};
             __syncthreads();
             for (int p = B.wave; p < FS_PC; p += NW)
-                lt[p * FS_LD + B.lane] = (p < M) ? G[(size_t)used[p] * K + istage] : 0.0;
+                lt[p * FS_LD + B.lane] = (p < M) ? G[(size_t)lused[p] * K + istage] : 0.0;
             __syncthreads();
-            for (int c = 0; c < n_chunk; c++) {
-                const int p0 = c * FS_PC;
-                const lptr_d cur = lt + (c & 1) * (FS_PC * FS_LD);
-                const lptr_d nxt = lt + ((c + 1) & 1) * (FS_PC * FS_LD);
-                if (c + 1 < n_chunk) {
-                    for (int p = B.wave; p < FS_PC; p += NW) {
-                        const int pp = p0 + FS_PC + p;
-                        nxt[p * FS_LD + B.lane] = (pp < M) ? G[(size_t)used[pp] * K + istage] : 0.0;
+            switch (nt) {
+            case 2: fs_pass<2>(Sig, G, lused, lt, ld, row_max, roff, M, K, n_chunk, istage, B.wave, B.lane, NW, kdiag, acc); break;
+            case 1: fs_pass<1>(Sig, G, lused, lt, ld, row_max, roff, M, K, n_chunk, istage, B.wave, B.lane, NW, kdiag, acc); break;
+            default:                                          // no row tile: still keep the barriers
+                for (int c = 0; c < n_chunk; c++) {
+                    if (c + 1 < n_chunk) {
+                        const lptr_d nxt = lt + ((c + 1) & 1) * (FS_PC * FS_LD);
+                        for (int p = B.wave; p < FS_PC; p += NW) {
+                            const int pp = (c + 1) * FS_PC + p;
+                            nxt[p * FS_LD + B.lane] = (pp < M) ? G[(size_t)lused[pp] * K + istage] : 0.0;
+                        }
                     }
+                    __syncthreads();
                 }
-                int pk = p0 + l4;
-                const lptr_d bcol = cur + l4 * FS_LD + sub * 16 + l15;
-                switch (nt) {
-                case 5: fs_chunk<5>(Sig, ld, row_max, roff, pk, bcol, acc); break;
-                case 4: fs_chunk<4>(Sig, ld, row_max, roff, pk, bcol, acc); break;
-                case 3: fs_chunk<3>(Sig, ld, row_max, roff, pk, bcol, acc); break;
-                case 2: fs_chunk<2>(Sig, ld, row_max, roff, pk, bcol, acc); break;
-                case 1: fs_chunk<1>(Sig, ld, row_max, roff, pk, bcol, acc); break;
-                default: break;
-                }
-                __syncthreads();
+                break;
             }
 #pragma unroll
             for (int t = 0; t < FS_JTW; t++) {
-                const int jt = jt0 + NG * t;
-                if (t < nt) {
+                if (jts[t] < nJ) {
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        const int j = jt * 16 + l4 + 4 * r;
+                        const int j = jts[t] * 16 + l4 + 4 * r;
                         if (j < M) {
-                            const double bj = G[(size_t)used[j] * K + icl];
-                            q_acc += acc[t][r] * bj;
-                            m_acc += bj * W.mu[j];
+                            const gptr_cd grow = G + (size_t)lused[j] * K;
+                            const double muj = W.mu[j];
+#pragma unroll
+                            for (int u = 0; u < 4; u++) {
+                                const int ic = i0 + u * 16 + l15;
+                                const double bj = grow[ic < K ? ic : K - 1];
+                                q_acc[u] += acc[t][u][r] * bj;
+                                m_acc[u] += bj * muj;
+                            }
                         }
                     }
                 }
             }
         }
-        q_acc += __shfl_xor(q_acc, 16, 64); q_acc += __shfl_xor(q_acc, 32, 64);
-        m_acc += __shfl_xor(m_acc, 16, 64); m_acc += __shfl_xor(m_acc, 32, 64);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            q_acc[u] += __shfl_xor(q_acc[u], 16, 64); q_acc[u] += __shfl_xor(q_acc[u], 32, 64);
+            m_acc[u] += __shfl_xor(m_acc[u], 16, 64); m_acc[u] += __shfl_xor(m_acc[u], 32, 64);
+        }
         __syncthreads();
         if (B.lane < 16) {
-            xred[B.wave * 16 + l15] = q_acc;
-            xred[(NW + B.wave) * 16 + l15] = m_acc;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                xred[B.wave * 64 + u * 16 + l15] = q_acc[u];
+                xred[(NW + B.wave) * 64 + u * 16 + l15] = m_acc[u];
+            }
         }
         __syncthreads();
         if (B.tid < 64 && i0 + B.tid < K) {
-            const int ss = B.tid >> 4, cc = B.tid & 15, i = i0 + B.tid;
+            const int i = i0 + B.tid;
             double q = 0, m = 0;
-            for (int gg = 0; gg < NG; gg++) {
-                q += xred[(gg * 4 + ss) * 16 + cc];
-                m += xred[(NW + gg * 4 + ss) * 16 + cc];
-            }
+            for (int w = 0; w < NW; w++) { q += xred[w * 64 + B.tid]; m += xred[(NW + w) * 64 + B.tid]; }
             W.Sin[i] = beta - beta * q * beta;
             W.Qin[i] = beta * (W.bt[i] - m);
         }
@@ -270,7 +340,17 @@ DEV void gm_fullstat(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmS
         if (i >= 1) W.gam[i] = 1 - W.Sig[(size_t)i * ld + i] * W.A[i];
     }
     blk_sync(B);
-    { PH_BEGIN(); gm_fullstat_features(B, F, W, K, M, beta); PH_END(PH_FS_FEAT); }
+    {
+        PH_BEGIN();
+#if defined(PAREBEN_PHASE_TIMERS) && !defined(PAREBEN_HOST_EMUL)
+        const long long ck0 = (B.tid == 0) ? (long long)clock64() : 0;
+#endif
+        gm_fullstat_features(B, F, W, K, M, beta);
+#if defined(PAREBEN_PHASE_TIMERS) && !defined(PAREBEN_HOST_EMUL)
+        if (B.tid == 0) S.ph[PH_FS_REST] += (long long)clock64() - ck0;     // shader-clock ticks of the same span
+#endif
+        PH_END(PH_FS_FEAT);
+    }
     gm_refresh_out(B, W, K);
     CNT(c.n_fullstat++; c.sum_m_full += M; c.sum_m2_full += (int64_t)M * M);
 }
