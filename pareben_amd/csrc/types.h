@@ -20,7 +20,7 @@ struct FoldDev {
     int N, nte;
 };
 
-// Per-fit counters (SURVEY.md 8(d) accounting); same meaning as oracle/eben_oracle.h.
+// Per-fit event counters (SURVEY.md 8(d) accounting).
 struct FitCounters {
     int64_t n_outer, n_inner, n_add, n_del, n_reest, n_fullstat;
     int64_t sum_m_action, sum_m_full, sum_m2_full, m_final, m_max, status;
