@@ -47,3 +47,13 @@ def synthetic_gaussian(n, p, n_causal=20, seed=20251004):
     beta = rng.standard_normal(n_causal)
     y = X[:, idx] @ beta + rng.standard_normal(n)
     return np.asfortranarray(X), y
+
+
+@pytest.fixture(scope="session")
+def yeast():
+    """Design of the stored real-R CrossValidate() run (paper_materials/.../10000_Features):
+    3803 x 10000 (+-1) genotypes and the phenotype; folds from R 3.5's sampler (the run used R 3.5.0)."""
+    d = np.load(os.path.join(GOLDEN, "yeast_looser10000.npz"))
+    n, p = int(d["n"]), int(d["p"])
+    G = np.unpackbits(d["bits"], axis=0)[:n].astype(np.float64) * 2.0 - 1.0
+    return np.asfortranarray(G), d["pheno"].astype(np.float64)

@@ -65,6 +65,19 @@ def main():
     np.savez_compressed(OUT + "/basis481_gm.npz", alpha=aa, lam=ll, fold_id=fid5, fold_err=E5,
                         counters=np.array([cnt5[k] for k in sorted(cnt5)]), counter_names=np.array(sorted(cnt5)))
 
+    # yeast design of the stored real-R run (10000_Features): filter_matrix_looser[, 2:10001] (+-1) and
+    # pheno1, bit-packed along samples (the tab-separated text is 512 MB; packed + deflated 60 kB)
+    yeast_txt = os.environ.get("YEAST_MATRIX", "/tmp/work/filter_matrix_looser")   # unzip of Full_Test/filter_matrix_looser.zip
+    if os.path.exists(yeast_txt):
+        rows = []
+        with open(yeast_txt) as f:
+            for line in f:
+                rows.append(np.array(line.split("\t", 10001)[1:10001], dtype=np.int8))
+        Gy = np.stack(rows)
+        ph = np.loadtxt(REF + "/paper_materials/Real Data Analysis/Full_Test/pheno1")
+        np.savez_compressed(OUT + "/yeast_looser10000.npz", bits=np.packbits((Gy > 0).astype(np.uint8), axis=0),
+                            n=np.int64(Gy.shape[0]), p=np.int64(Gy.shape[1]), pheno=ph)
+
     # numbers recorded in SURVEY.md section 10 (compiled reference C, survey session)
     known = {
         "config1": {

@@ -1,0 +1,38 @@
+"""Full-table parity against the stored real-R CrossValidate() output: all
+400 cells x 3 folds of the yeast p=10000 run on the GPU, compared with Results.Detail$MSE,
+Results.Summary and (alpha*, lambda*).  Writes a JSON report (default profiles/yeast_full_table.json)."""
+import json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import pareben_amd
+from pareben_amd.grid import AssignToFolds, summarise_cv
+
+g = os.path.join(ROOT, "tests", "golden")
+d = np.load(os.path.join(g, "yeast_looser10000.npz")); r = np.load(os.path.join(g, "rds_10000.npz"))
+n = int(d["n"]); G = np.asfortranarray(np.unpackbits(d["bits"], axis=0)[:n].astype(np.float64) * 2 - 1); y = d["pheno"].astype(np.float64)
+fid = AssignToFolds(G, 3, sample_kind="Rounding")
+ncell = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+sel = np.arange(400)[:ncell]
+alpha = r["detail_alpha"][::3][sel]; lam = r["detail_lambda"][::3][sel]
+want = r["detail_MSE"].reshape(400, 3)[sel]
+t0 = time.time()
+with pareben_amd.Context(G, y, fid, 3) as ctx:
+    E, st, cnt = ctx.run(alpha, lam)
+    timing = ctx.last_timing()
+wall = time.time() - t0
+rel = np.abs(E - want) / want
+rep = {"cells": int(ncell), "fits": int(E.size), "wall_s": wall, "kernel_ms": timing,
+       "max_rel_diff_fold_sse": float(rel.max()), "n_rel_gt_1e-6": int((rel > 1e-6).sum()), "n_rel_gt_1e-9": int((rel > 1e-9).sum()),
+       "aborted": int((st & 8 != 0).sum()), "stale_path": int((st & 4 != 0).sum()), "max_active": int(cnt[..., 10].max())}
+if ncell == 400:
+    a_s, l_s, se, cv, idx = summarise_cv(alpha, lam, E, 3)
+    rep.update(alpha_opt=float(a_s[idx]), lambda_opt=float(l_s[idx]), cv_error=float(cv[idx]),
+               r_alpha_opt=float(r["alpha_optimal"][0]), r_lambda_opt=float(r["lambda_optimal"][0]),
+               selected_equal=bool(a_s[idx] == r["alpha_optimal"][0] and l_s[idx] == r["lambda_optimal"][0]),
+               max_rel_diff_summary_mse=float(np.max(np.abs(cv - r["summary_MSE"]) / r["summary_MSE"])),
+               max_rel_diff_summary_se=float(np.max(np.abs(se - r["summary_SE"]) / r["summary_SE"])))
+out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "yeast_full_table.json")
+os.makedirs(os.path.dirname(out), exist_ok=True)
+json.dump(rep, open(out, "w"), indent=1)
+print(json.dumps(rep))
