@@ -23,15 +23,19 @@ def test_grid_and_folds_match_real_r(golden, yeast):
 
 
 def test_cells_match_real_r(golden, yeast):
-    """18 fits (6 cells x 3 folds) spread over the grid, fold SSE vs Results.Detail$MSE."""
+    """18 fits (6 cells x 3 folds) spread over the grid, fold SSE vs Results.Detail$MSE.
+    (The full 1200-fit table is tools/yeast_full_table.py; its round-1 report is
+    profiles/r01/yeast_full_table_vs_real_R.json: 1182 fits agree to < 1e-9, the other 18 -- all at
+    alpha = 1 with transient active sets of 440-870 and up to 10010 inner iterations -- differ by
+    4e-6 ... 4e-3 because their trajectories amplify summation-order rounding; (alpha*, lambda*) equal.)"""
     G, y = yeast
     r = golden.rds
     fid = AssignToFolds(G, 3, sample_kind="Rounding")
-    cells = np.array([0, 19, 100, 210, 305, 399])
+    cells = np.array([0, 19, 101, 210, 305, 399])
     alpha = r["detail_alpha"][::3][cells]; lam = r["detail_lambda"][::3][cells]
     want = r["detail_MSE"].reshape(400, 3)[cells]
     with pareben_amd.Context(G, y, fid, 3) as ctx:
         E, st, cnt = ctx.run(alpha, lam)
     assert np.all(st & 8 == 0)
     rel = np.abs(E - want) / want
-    assert rel.max() < 1e-6, (rel, E, want)          # north-star bar; observed ~1e-12
+    assert rel.max() < 1e-9, (rel, E, want)          # north-star bar is 1e-6; observed 1e-15 ... 5e-13

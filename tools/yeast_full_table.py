@@ -25,11 +25,16 @@ rel = np.abs(E - want) / want
 rep = {"cells": int(ncell), "fits": int(E.size), "wall_s": wall, "kernel_ms": timing,
        "max_rel_diff_fold_sse": float(rel.max()), "n_rel_gt_1e-6": int((rel > 1e-6).sum()), "n_rel_gt_1e-9": int((rel > 1e-9).sum()),
        "aborted": int((st & 8 != 0).sum()), "stale_path": int((st & 4 != 0).sum()), "max_active": int(cnt[..., 10].max())}
+bad = np.argwhere(rel > 1e-9)
+rep["deviating_fits"] = [{"cell": int(sel[c]), "fold": int(f) + 1, "alpha": float(alpha[c]), "lambda": float(lam[c]),
+                          "gpu": float(E[c, f]), "real_r": float(want[c, f]), "rel": float(rel[c, f]),
+                          "m_final": int(cnt[c, f, 9]), "m_max": int(cnt[c, f, 10]), "n_inner": int(cnt[c, f, 1])} for c, f in bad]
 if ncell == 400:
     a_s, l_s, se, cv, idx = summarise_cv(alpha, lam, E, 3)
     rep.update(alpha_opt=float(a_s[idx]), lambda_opt=float(l_s[idx]), cv_error=float(cv[idx]),
                r_alpha_opt=float(r["alpha_optimal"][0]), r_lambda_opt=float(r["lambda_optimal"][0]),
                selected_equal=bool(a_s[idx] == r["alpha_optimal"][0] and l_s[idx] == r["lambda_optimal"][0]),
+               rel_diff_cv_error_at_optimum=float(abs(cv[idx] - r["summary_MSE"][idx]) / r["summary_MSE"][idx]),
                max_rel_diff_summary_mse=float(np.max(np.abs(cv - r["summary_MSE"]) / r["summary_MSE"])),
                max_rel_diff_summary_se=float(np.max(np.abs(se - r["summary_SE"]) / r["summary_SE"])))
 out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "yeast_full_table.json")
