@@ -1,0 +1,654 @@
+// bm_fit.h -- one binomial (logistic) main-effect EBEN fit executed by ONE workgroup.
+//
+// What it computes is what EBEN_orig/src/ElasticNetBinaryNEmainEff.c computes for one
+// (training fold, alpha, lambda): the outer loop (:329-344) around the inner
+// add / re-estimate / delete ascent (:397-827) with a Laplace (IRLS) posterior mode
+// (fEBCatPostModeBmNeEN :1808-2010) after every block of actions.
+//
+// The per-sample IRLS weights w = y(1-y) change at every mode update, so unlike the Gaussian
+// kernel nothing can be cached as a Gram matrix: every action needs the weighted cross products
+// BP[i][p] = x_i' diag(w) Phi_p / |x_i| of all K features with the M model columns.  They are
+// computed once per (mode update / action) by the whole workgroup -- one wavefront per feature,
+// lanes over samples (coalesced columns), xor-shuffle reductions -- into a K x M scratch matrix in
+// HBM and then reused by the M^2-per-feature quadratic forms.  Phi is never materialised: column 0
+// is the intercept, column l+1 is the design column of used[l] times 1/|x|.
+//
+// Reference quirks kept: Q1 first basis = column 0, force-deleted once;
+// Q12 the outer stopping sum covers M = N_used+1 precisions (one stale slot); Q15 add-priority
+// never fires; the re-estimate S/Q update reads the already updated Sigma row; the Newton loop
+// keeps the y of a rejected line search.
+#pragma once
+#include "blk.h"
+#include "types.h"
+#include "gm_fit.h"      // action codes, GmScalars, counters, gm_spd_inverse
+
+struct BmWork {
+    double *Sin, *Qin, *Sout, *Qout, *dml, *aroot, *bb;   // K each
+    int *upos, *todo;                                      // K each
+    signed char *act;                                      // K
+    double *Sig, *H;                                       // ld x ld, column-major
+    double *A, *mu, *g, *dmu, *mnew, *tmp, *tp, *v3, *v4;  // ld each
+    int *used;                                             // ld
+    double *w, *pm, *yv, *e, *bphi;                        // Nmax each
+    double *BP;                                            // K x ld (row i = feature i)
+    int cap, ld;                                           // cap = max model size M, ld = cap
+};
+
+// model column p at sample h
+#define BM_PHI(p, h) ((p) == 0 ? 1.0 : F.X[(size_t)W.used[(p) - 1] * N + (h)] * F.rscale[W.used[(p) - 1]])
+
+// a GmWork view so the Gaussian kernel's SPD inverse can be reused on (Sig, ld)
+DEV GmWork bm_as_gm(const BmWork &W)
+{
+    GmWork G{};
+    G.Sig = W.Sig; G.H = W.H; G.v3 = W.v3; G.v4 = W.v4; G.cap = W.cap; G.ld = W.ld;
+    return G;
+}
+
+// pm[h] = sum_p Phi_p[h] * mu[p]
+DEVNI void bm_phi_mu(const Blk &B, const FoldDev &F, const BmWork &W, int M, const double *mu, double *out)
+{
+    const int N = F.N;
+    PAR(h, N) {
+        double a = 0;
+        for (int p = 0; p < M; p++) a += BM_PHI(p, h) * mu[p];
+        out[h] = a;
+    }
+    blk_sync(B);
+}
+
+// y = sigmoid(pm); returns -sum t log y + (1-t) log(1-y)  (:2013-2032)
+DEVNI double bm_data_error(const Blk &B, const FoldDev &F, const BmWork &W)
+{
+    const int N = F.N;
+    double part = 0;
+    PAR(h, N) {
+        const double y = 1 / (1 + exp(-W.pm[h]));
+        W.yv[h] = y;
+        const double t = F.y[h];
+        if (y != 0) part -= t * log(y);
+        if (y != 1) part -= (1 - t) * log(1 - y);
+    }
+    const double s = blk_sum(B, part);
+    return s;
+}
+
+// BP[i][p] = sum_h x_i[h] w[h] Phi_p[h] / |x_i| for all features i and model columns p < M;
+// also bb-style single columns through `only` (>= 0: only that column, written to W.bb).
+DEVNI void bm_weighted_rows(const Blk &B, const FoldDev &F, const BmWork &W, int K, int M)
+{
+    const int N = F.N, ld = W.ld;
+#ifdef PAREBEN_HOST_EMUL
+    for (int i = 0; i < K; i++)
+        for (int p = 0; p < M; p++) {
+            double a = 0;
+            for (int h = 0; h < N; h++) a += (F.X[(size_t)i * N + h] * W.w[h]) * BM_PHI(p, h);
+            W.BP[(size_t)i * ld + p] = a / F.scale[i];
+        }
+#else
+    for (int i = B.wave; i < K; i += B.nwave) {
+        const double *x = F.X + (size_t)i * N;
+        for (int p = 0; p < M; p++) {
+            double a = 0;
+            if (p == 0) { for (int h = B.lane; h < N; h += 64) a += x[h] * W.w[h]; }
+            else {
+                const int u = W.used[p - 1];
+                const double *xu = F.X + (size_t)u * N;
+                const double r = F.rscale[u];
+                for (int h = B.lane; h < N; h += 64) a += (x[h] * W.w[h]) * (xu[h] * r);
+            }
+            a = wave_sum(a);
+            if (B.lane == 0) W.BP[(size_t)i * ld + p] = a / F.scale[i];
+        }
+    }
+#endif
+    blk_sync(B);
+}
+
+// posterior mode, :1808-2010.  Leaves w, Sig (= H^-1), H from its last Hessian evaluation.
+DEVNI int bm_postmode(const Blk &B, const FoldDev &F, const BmWork &W, GmScalars &S)
+{
+    const int N = F.N, M = S.M, ld = W.ld;
+    const double step_min = 1.0 / 256.0;
+    bm_phi_mu(B, F, W, M, W.mu, W.pm);
+    double derr = bm_data_error(B, F, W);
+    double rp = 0;
+    PAR(i, M) if (i >= 1) rp += W.A[i - 1] * W.mu[i] * W.mu[i] / 2;
+    double total = blk_sum(B, rp) + derr;
+    for (int it = 0; it < 25; it++) {
+        const double elog = total;
+        double gp = 0, hp = 0;
+        PAR(h, N) {
+            const double y = W.yv[h];
+            const double e = F.y[h] - y;
+            W.e[h] = e;
+            double b = y * (1 - y);
+            if (b < 1e-10) b = 1e-5;
+            if (b > 1e10) b = 1e5;
+            W.w[h] = b;
+            gp += e; hp += b;
+        }
+        const double g0 = blk_sum(B, gp), h0 = blk_sum(B, hp);
+        // gradient and first Hessian row/column: one wavefront per model column
+#ifdef PAREBEN_HOST_EMUL
+        for (int j = 1; j < M; j++) {
+            double ga = 0, ha = 0;
+            for (int h = 0; h < N; h++) { const double ph = BM_PHI(j, h); ga += W.e[h] * ph; ha += W.w[h] * ph; }
+            W.g[j] = ga - W.A[j - 1] * W.mu[j];
+            W.H[j] = ha; W.H[(size_t)j * ld] = ha;
+        }
+        for (int j = 1; j < M; j++)
+            for (int k = 1; k <= j; k++) {
+                double a = 0;
+                for (int h = 0; h < N; h++) a += BM_PHI(j, h) * W.w[h] * BM_PHI(k, h);
+                if (j == k) a += W.A[k - 1];
+                W.H[(size_t)k * ld + j] = a; W.H[(size_t)j * ld + k] = a;
+            }
+#else
+        for (int j = 1 + B.wave; j < M; j += B.nwave) {
+            double ga = 0, ha = 0;
+            for (int h = B.lane; h < N; h += 64) { const double ph = BM_PHI(j, h); ga += W.e[h] * ph; ha += W.w[h] * ph; }
+            ga = wave_sum(ga); ha = wave_sum(ha);
+            if (B.lane == 0) { W.g[j] = ga - W.A[j - 1] * W.mu[j]; W.H[j] = ha; W.H[(size_t)j * ld] = ha; }
+        }
+        {   // lower triangle of Phi' diag(w) Phi, one wavefront per (j, k) pair
+            const int np = (M - 1) * M / 2;
+            for (int q = B.wave; q < np; q += B.nwave) {
+                int j = (int)((sqrt(8.0 * q + 1.0) - 1.0) * 0.5);
+                while ((j + 1) * (j + 2) / 2 <= q) j++;
+                while (j * (j + 1) / 2 > q) j--;
+                const int k = q - j * (j + 1) / 2 + 1;
+                j += 1;                                        // 1 <= k <= j <= M-1
+                const int uj = W.used[j - 1], uk = W.used[k - 1];
+                const double *xj = F.X + (size_t)uj * N, *xk = F.X + (size_t)uk * N;
+                const double rj = F.rscale[uj], rk = F.rscale[uk];
+                double a = 0;
+                for (int h = B.lane; h < N; h += 64) a += (xj[h] * rj) * W.w[h] * (xk[h] * rk);
+                a = wave_sum(a);
+                if (B.lane == 0) {
+                    if (j == k) a += W.A[k - 1];
+                    W.H[(size_t)k * ld + j] = a; W.H[(size_t)j * ld + k] = a;
+                }
+            }
+        }
+#endif
+        if (B.tid == 0) { W.g[0] = g0; W.H[0] = h0; }
+        blk_sync(B);
+        for (int j = B.wave; j < M; j += B.nwave)
+            for (int i = B.lane; i < M; i += BLK_LANES) W.Sig[(size_t)j * ld + i] = W.H[(size_t)j * ld + i];
+        blk_sync(B);
+        {
+            const GmWork G = bm_as_gm(W);
+            if (gm_spd_inverse(B, G, M)) return 1;
+        }
+        blk_sync(B);
+        int cp = 0;
+        PAR(j, M) if (j >= 1 && fabs(W.g[j]) < 1e-6) cp++;
+        const int cnt = blk_isum(B, cp);
+        if (cnt == M - 1) break;
+        PAR(k, M) {
+            double a = 0;
+            for (int L = 0; L < M; L++) a += W.g[L] * W.Sig[(size_t)L * ld + k];
+            W.dmu[k] = a;
+        }
+        blk_sync(B);
+        double step = 1;
+        while (step > step_min) {
+            PAR(j, M) W.mnew[j] = W.mu[j] + step * W.dmu[j];
+            blk_sync(B);
+            bm_phi_mu(B, F, W, M, W.mnew, W.pm);
+            derr = bm_data_error(B, F, W);
+            double rq = 0;
+            PAR(j, M) if (j >= 1) rq += W.A[j - 1] * W.mnew[j] * W.mnew[j] / 2;
+            total = derr + blk_sum(B, rq);
+            if (total >= elog) step = step / 2;
+            else {
+                PAR(j, M) W.mu[j] = W.mnew[j];
+                blk_sync(B);
+                step = 0;
+            }
+        }
+    }
+    blk_sync(B);
+    return 0;
+}
+
+// full statistics, :1633-1803
+DEVNI int bm_fullstat(const Blk &B, const FoldDev &F, const BmWork &W, int K, GmScalars &S)
+{
+    const int N = F.N, ld = W.ld;
+    if (bm_postmode(B, F, W, S)) return 1;
+    const int M = S.M;
+    bm_phi_mu(B, F, W, M, W.mu, W.pm);
+    PAR(h, N) { const double y = 1 / (1 + exp(-W.pm[h])); W.e[h] = F.y[h] - y; }
+    blk_sync(B);
+    bm_weighted_rows(B, F, W, K, M);
+    // S_in = x_i' diag(w) x_i / |x_i|^2 - BP_i' Sigma BP_i ;  Q_in = x_i' e / |x_i|
+#ifdef PAREBEN_HOST_EMUL
+    for (int i = 0; i < K; i++) {
+        double bbq = 0, ze = 0;
+        for (int h = 0; h < N; h++) { const double x = F.X[(size_t)i * N + h]; bbq += W.w[h] * (x * x); ze += x * W.e[h]; }
+        W.bb[i] = bbq; W.aroot[i] = ze;        // scratch: aroot is rewritten by every dML pass
+    }
+#else
+    for (int i = B.wave; i < K; i += B.nwave) {
+        const double *x = F.X + (size_t)i * N;
+        double bbq = 0, ze = 0;
+        for (int h = B.lane; h < N; h += 64) { const double xv = x[h]; bbq += W.w[h] * (xv * xv); ze += xv * W.e[h]; }
+        bbq = wave_sum(bbq); ze = wave_sum(ze);
+        if (B.lane == 0) { W.bb[i] = bbq; W.aroot[i] = ze; }
+    }
+#endif
+    blk_sync(B);
+    PAR(i, K) {
+        const double *bp = W.BP + (size_t)i * ld;
+        double quad = 0;
+        for (int p = 0; p < M; p++) {
+            double t = 0;
+            for (int q = 0; q < M; q++) t += W.Sig[(size_t)p * ld + q] * bp[q];
+            quad += t * bp[p];
+        }
+        const double sc = F.scale[i];
+        W.Sin[i] = W.bb[i] / (sc * sc) - quad;
+        W.Qin[i] = W.aroot[i] / sc;
+    }
+    blk_sync(B);
+    PAR(i, K) {
+        const double s = W.Sin[i], q = W.Qin[i];
+        const int l = W.upos[i];
+        if (l >= 0) { const double a = W.A[l]; W.Sout[i] = a * s / (a - s); W.Qout[i] = a * q / (a - s); }
+        else { W.Sout[i] = s; W.Qout[i] = q; }
+    }
+    blk_sync(B);
+    CNT(c.n_fullstat++; c.sum_m_full += M; c.sum_m2_full += (int64_t)M * M);
+    return 0;
+}
+
+// dML / action choice, :2063-2238 (Q15: only delete-priority can fire)
+DEVNI int bm_delta_ml(const Blk &B, const BmWork &W, int K, int N, int NU, double lambda, double alpha,
+                      int *any_del_out, double *best)
+{
+    const double l1 = lambda * alpha, l2 = lambda * (1 - alpha);
+    int prio_add = 0, prio_del = 0;
+    if (NU < 10) { prio_add = 1; prio_del = 0; }
+    if (NU > 100 || NU >= N) { prio_add = 0; prio_del = 1; }
+    int my_del = 0;
+    PAR(i, K) {
+        const int l = W.upos[i];
+        if (l == UP_LOST) { W.act[i] = ACT_NONE; continue; }
+        const double so = W.Sout[i], qo = W.Qout[i];
+        double d_ml = 0;
+        int act = ACT_NONE;
+        const double a = so - qo * qo + 2 * l1 + l2;
+        const double bq = (so + l2) * (so + 4 * l1 + l2);
+        const double g = 2 * l1 * (so + l2) * (so + l2);
+        const double disc = bq * bq - 4 * a * g;
+        if (a < 0 && disc > 0) {
+            const double r = (-bq - sqrt(disc)) / (2 * a);
+            const double L = (log(r / (r + so + l2)) + qo * qo / (r + so + l2)) * 0.5 - l1 / r;
+            if (L > 0) {
+                W.aroot[i] = r + l2;
+                if (l >= 0) {
+                    act = ACT_REEST;
+                    const double o = W.A[l] - l2;
+                    d_ml = 0.5 * (log(r * (o + so + l2) / (o * (r + so + l2))) +
+                                  qo * qo * (1 / (r + so + l2) - 1 / (o + so + l2))) -
+                           l1 * (1 / r - 1 / o);
+                } else { act = ACT_ADD; d_ml = L; }
+            }
+        } else if (l >= 0 && NU > 1) {
+            my_del = 1;
+            act = ACT_DEL;
+            const double o = W.A[l] - l2;
+            const double L = (log(o / (o + so + l2)) + qo * qo / (o + so + l2)) * 0.5 - l1 / o;
+            d_ml = -L;
+        }
+        W.act[i] = (signed char)act;
+        W.dml[i] = d_ml;
+    }
+    const int any_del = blk_or(B, my_del);
+    *any_del_out = any_del;
+    bool rescanned = false;
+    if (any_del && prio_del) {
+        PAR(i, K) {
+            const int act = W.act[i];
+            if (act == ACT_REEST) W.dml[i] = 0;
+            else if (act == ACT_ADD) { if (!prio_add) W.dml[i] = 0; }
+        }
+        rescanned = true;
+    }
+    blk_sync(B);
+    double v = 0; int idx = 0x7fffffff;
+    PAR(i, K) {
+        if (!rescanned && W.upos[i] == UP_LOST) continue;
+        const double d = W.dml[i];
+        if (d > v) { v = d; idx = i; }
+    }
+    double bv; int bi;
+    blk_argmax(B, v, idx, &bv, &bi);
+    if (!(bv > 0)) { bv = 0; bi = 0; }
+    *best = bv;
+    return bi;
+}
+
+DEVNI int bm_collect(const Blk &B, const BmWork &W, int K, double cutoff)
+{
+    int base = 0;
+    for (int i0 = 0; i0 < K; i0 += B.nthr) {
+        const int i = i0 + B.tid;
+        const int f = (i < K && W.dml[i] >= cutoff) ? 1 : 0;
+        int tot;
+        const int off = blk_scan_excl(B, f, &tot);
+        if (f) W.todo[base + off] = i;
+        base += tot;
+    }
+    blk_sync(B);
+    return base;
+}
+
+// add feature nu, :830-1003 + :701-711
+DEVNI void bm_add(const Blk &B, const FoldDev &F, const BmWork &W, int K, GmScalars &S, int nu, double newA)
+{
+    const int N = F.N, M = S.M, ld = W.ld, NU = M - 1;
+    const double rn = F.rscale[nu];
+    PAR(h, N) W.bphi[h] = W.w[h] * (F.X[(size_t)nu * N + h] * rn);
+    blk_sync(B);
+    // bb[i] = x_i' (w .* phi) / |x_i| ; tmp[p] = Phi_p' (w .* phi)
+#ifdef PAREBEN_HOST_EMUL
+    for (int i = 0; i < K; i++) { double a = 0; for (int h = 0; h < N; h++) a += F.X[(size_t)i * N + h] * W.bphi[h]; W.bb[i] = a / F.scale[i]; }
+    for (int p = 0; p < M; p++) { double a = 0; for (int h = 0; h < N; h++) a += BM_PHI(p, h) * W.bphi[h]; W.tmp[p] = a; }
+#else
+    for (int i = B.wave; i < K; i += B.nwave) {
+        const double *x = F.X + (size_t)i * N;
+        double a = 0;
+        for (int h = B.lane; h < N; h += 64) a += x[h] * W.bphi[h];
+        a = wave_sum(a);
+        if (B.lane == 0) W.bb[i] = a / F.scale[i];
+    }
+    for (int p = B.wave; p < M; p += B.nwave) {
+        double a = 0;
+        for (int h = B.lane; h < N; h += 64) a += BM_PHI(p, h) * W.bphi[h];
+        a = wave_sum(a);
+        if (B.lane == 0) W.tmp[p] = a;
+    }
+#endif
+    blk_sync(B);
+    PAR(i, M) {
+        double a = 0;
+        for (int j = 0; j < M; j++) a += W.Sig[(size_t)j * ld + i] * W.tmp[j];
+        W.tp[i] = a;
+    }
+    const double sii = 1.0 / (newA + W.Sin[nu]);
+    const double mui = sii * W.Qin[nu];
+    blk_sync(B);
+    bm_weighted_rows(B, F, W, K, M);                           // rows against the OLD model columns
+    PAR(i, K) {
+        const double *bp = W.BP + (size_t)i * ld;
+        double t = 0;
+        for (int j = 0; j < M; j++) t += bp[j] * W.tp[j];
+        const double mc = W.bb[i] - t;
+        W.Sin[i] = W.Sin[i] - mc * mc * sii;
+        W.Qin[i] = W.Qin[i] - mui * mc;
+    }
+    PAR(i, M) W.mu[i] += -mui * W.tp[i];
+    for (int j = B.wave; j < M; j += B.nwave) {
+        const double f = sii * W.tp[j];
+        for (int i = B.lane; i < M; i += BLK_LANES) W.Sig[(size_t)j * ld + i] += f * W.tp[i];
+    }
+    PAR(i, M) {
+        const double si = -sii * W.tp[i];
+        W.Sig[(size_t)M * ld + i] = si;
+        W.Sig[(size_t)i * ld + M] = si;
+    }
+    if (B.tid == 0) {
+        W.Sig[(size_t)M * ld + M] = sii;
+        W.A[NU] = newA;
+        W.mu[M] = mui;
+        W.used[NU] = nu;
+        W.upos[nu] = NU;
+    }
+    S.M = M + 1;
+    blk_sync(B);
+}
+
+// delete used slot jj (feature nu), :1010-1121 + :728-744
+DEVNI void bm_delete(const Blk &B, const FoldDev &F, const BmWork &W, int K, GmScalars &S, int jj, int nu)
+{
+    const int M = S.M, ld = W.ld, last = M - 1, j1 = jj + 1;
+    PAR(i, M) W.tp[i] = W.Sig[(size_t)j1 * ld + i];
+    blk_sync(B);
+    const double sjj = W.tp[j1];
+    const double mujj = W.mu[j1];
+    const int gone = W.used[jj];
+    bm_weighted_rows(B, F, W, K, M);
+    PAR(i, K) {
+        const double *bp = W.BP + (size_t)i * ld;
+        double t = 0;
+        for (int j = 0; j < M; j++) t += bp[j] * W.tp[j];
+        W.Sin[i] = W.Sin[i] + t * t / sjj;
+        W.Qin[i] = W.Qin[i] + t * mujj / sjj;
+    }
+    PAR(i, M) W.mu[i] = W.mu[i] - mujj * W.tp[i] / sjj;
+    for (int j = B.wave; j < M; j += B.nwave) {
+        const double vj = W.tp[j];
+        for (int i = B.lane; i < M; i += BLK_LANES) W.Sig[(size_t)j * ld + i] -= W.tp[i] * vj / sjj;
+    }
+    blk_sync(B);
+    if (j1 != last) {
+        PAR(i, M) { W.v3[i] = W.Sig[(size_t)last * ld + i]; W.v4[i] = W.Sig[(size_t)i * ld + last]; }
+        blk_sync(B);
+        PAR(i, last) {
+            if (i != j1) { W.Sig[(size_t)j1 * ld + i] = W.v3[i]; W.Sig[(size_t)i * ld + j1] = W.v4[i]; }
+        }
+        if (B.tid == 0) {
+            W.Sig[(size_t)j1 * ld + j1] = W.v3[last];
+            W.A[jj] = W.A[last - 1];
+            W.mu[j1] = W.mu[last];
+            W.used[jj] = W.used[last - 1];
+            W.upos[W.used[last - 1]] = jj;
+        }
+    }
+    if (B.tid == 0) W.upos[gone] = (gone == nu) ? UP_FREE : UP_LOST;
+    S.M = last;
+    blk_sync(B);
+}
+
+// re-estimate used slot jj, :1127-1203 (S/Q update reads the NEW Sigma row j1)
+DEVNI void bm_reestimate(const Blk &B, const FoldDev &F, const BmWork &W, int K, GmScalars &S, int jj, double newA)
+{
+    const int M = S.M, ld = W.ld, j1 = jj + 1;
+    PAR(i, M) W.tp[i] = W.Sig[(size_t)j1 * ld + i];
+    blk_sync(B);
+    const double oldA = W.A[jj];
+    const double dinv = 1.0 / (newA - oldA);
+    const double kappa = 1.0 / (W.tp[j1] + dinv);
+    const double mujj = W.mu[j1];
+    blk_sync(B);
+    if (B.tid == 0) W.A[jj] = newA;
+    PAR(i, M) W.mu[i] += (-mujj * kappa) * W.tp[i];
+    for (int j = B.wave; j < M; j += B.nwave) {
+        const double f = kappa * W.tp[j];
+        for (int i = B.lane; i < M; i += BLK_LANES) W.Sig[(size_t)j * ld + i] -= f * W.tp[i];
+    }
+    blk_sync(B);
+    PAR(i, M) W.tmp[i] = W.Sig[(size_t)j1 * ld + i];           // the updated row
+    blk_sync(B);
+    bm_weighted_rows(B, F, W, K, M);
+    PAR(i, K) {
+        const double *bp = W.BP + (size_t)i * ld;
+        double t = 0;
+        for (int j = 0; j < M; j++) t += bp[j] * W.tmp[j];
+        W.Sin[i] = W.Sin[i] + t * t * kappa;
+        W.Qin[i] = W.Qin[i] + mujj * kappa * t;
+    }
+    blk_sync(B);
+}
+
+// one call of the inner routine, :397-827.  *loglik = training log-likelihood at exit.
+DEV int bm_inner(const Blk &B, const FoldDev &F, const BmWork &W, int K, double lambda, double alpha,
+                 GmScalars &S, int iter, double *loglik)
+{
+    const int N = F.N;
+    const bool first = iter <= 1;
+    if (first) {                                               // :1225-1385
+        S.M = 2;
+        PAR(i, K) W.upos[i] = UP_FREE;
+        blk_sync(B);
+        double pa = 0, pb = 0, pc = 0, pd = 0;
+        const double r0 = F.rscale[0];
+        PAR(h, N) {
+            const double tp = -1 + 2 * F.y[h];
+            const double lo = log(((tp * 0.9 + 1) / 2) / (1 - (tp * 0.9 + 1) / 2));
+            const double ph = F.X[h] * r0;
+            pa += ph; pb += ph * ph; pc += lo; pd += ph * lo;
+        }
+        const double sa = blk_sum(B, pa), sb = blk_sum(B, pb), sc = blk_sum(B, pc), sd = blk_sum(B, pd);
+        if (B.tid == 0) {
+            W.used[0] = 0; W.upos[0] = 0;
+            const double det = (double)N * sb - sa * sa;
+            double m0, m1;
+            if (fabs(det) > 1e-10 * N * (sb > 0 ? sb : 1)) { m0 = (sb * sc - sa * sd) / det; m1 = ((double)N * sd - sa * sc) / det; }
+            else { const double c0 = sa / N, den = (double)N * (1 + c0 * c0); m0 = sc / den; m1 = c0 * sc / den; }
+            W.mu[0] = m0; W.mu[1] = m1;
+            double a0 = (m1 == 0) ? 1 : 1 / (m1 * m1);
+            if (a0 < 1e-3) a0 = 1e-3;
+            if (a0 > 1e3) a0 = 1e3;
+            W.A[0] = a0;
+        }
+    } else {
+        PAR(i, K) if (W.upos[i] == UP_LOST) W.upos[i] = UP_FREE;
+    }
+    blk_sync(B);
+    const int initial = W.used[0];
+    int ini_removed = first ? 0 : 1;
+    if (bm_fullstat(B, F, W, K, S)) { S.status |= ST_CHOLESKY | ST_ABORT; return 1; }
+    int sel = ACT_NONE, jj = -1, n_todo = 0, last_it = 0, i_iter = 0;
+    const int it_max = iter == 1 ? 10 : 100;
+    double ll = 1e-30, ll0;
+    while (!last_it) {
+        i_iter++;
+        CNT(c.n_inner++);
+        ll0 = ll;
+        double best; int any_del;
+        int nu = bm_delta_ml(B, W, K, N, S.M - 1, lambda, alpha, &any_del, &best);
+        int worthwhile;
+        if (sel == ACT_TERM && !ini_removed && S.M > 2) nu = -1;
+        if (nu == -1 && ini_removed) { worthwhile = 0; sel = ACT_TERM; }
+        else if (nu == -1 && !ini_removed && S.M > 2) {
+            worthwhile = 1;
+            nu = initial;
+            if (B.tid == 0) { W.act[nu] = ACT_DEL; W.todo[0] = initial; }
+            blk_sync(B);
+            n_todo = 1; ini_removed = 1; sel = ACT_DEL;
+        } else {
+            worthwhile = 1;
+            const int act_nu = W.act[nu];
+            double cutoff = best * (act_nu == ACT_ADD ? 0.90 : 1.0);
+            if (cutoff < 0.001) cutoff = 0.001;
+            n_todo = bm_collect(B, W, K, cutoff);
+            if (act_nu == ACT_DEL && n_todo > 1) n_todo = 1;
+            if (n_todo == 0) worthwhile = 0;
+        }
+        if (!worthwhile) sel = ACT_TERM;
+        if (worthwhile) {
+            for (int u = 0; u < n_todo; u++) {
+                nu = W.todo[u];
+                sel = W.act[nu];
+                const double newA = W.aroot[nu];
+                if (sel == ACT_REEST || sel == ACT_DEL) {
+                    const int l = W.upos[nu];
+                    if (l >= 0) jj = l;
+                    else { S.status |= ST_STALE; if (jj < 0 || jj >= S.M - 1) { S.status |= ST_ABORT; return 1; } }
+                }
+                if (sel == ACT_REEST && fabs(log(newA) - log(W.A[jj])) <= 1e-3 && any_del == 0) sel = ACT_TERM;
+                blk_sync(B);
+                if (sel == ACT_REEST) {
+                    CNT(c.n_reest++; c.sum_m_action += S.M);
+                    bm_reestimate(B, F, W, K, S, jj, newA);
+                } else if (sel == ACT_ADD) {
+                    if (S.M + 1 > W.cap) { S.status |= ST_OVERFLOW | ST_ABORT; return 1; }
+                    CNT(c.n_add++; c.sum_m_action += S.M);
+                    bm_add(B, F, W, K, S, nu, newA);
+                } else if (sel == ACT_DEL) {
+                    CNT(c.n_del++; c.sum_m_action += S.M);
+                    bm_delete(B, F, W, K, S, jj, nu);
+                    if (nu == initial) ini_removed = 1;
+                }
+                CNT(if (S.M > c.m_max) c.m_max = S.M);
+                if (u == n_todo - 1) {                         // :749-762
+                    if (bm_fullstat(B, F, W, K, S)) { S.status |= ST_CHOLESKY | ST_ABORT; return 1; }
+                }
+            }
+        }
+        if (sel == ACT_TERM && ini_removed) last_it = 1;
+        if ((i_iter == it_max && S.M == 2) || i_iter > it_max) last_it = 1;
+        if (i_iter == it_max) sel = ACT_TERM;
+        bm_phi_mu(B, F, W, S.M, W.mu, W.pm);
+        double lp = 0;
+        PAR(h, N) {
+            const double ex = exp(W.pm[h]);
+            lp += F.y[h] * log(ex / (1 + ex)) + (1 - F.y[h]) * log(1 / (1 + ex));
+        }
+        ll = blk_sum(B, lp);
+        const double dL = fabs((ll - ll0) / ll0);
+        if (dL < 1e-3) sel = ACT_TERM;
+    }
+    *loglik = ll;
+    return 0;
+}
+
+// The whole fit, :236-389.  On return W.mu[0] is the intercept, W.mu[l+1] the weight of used[l]
+// (normalised-column units), S.M the model size incl. the intercept.
+DEV void bm_fit(const Blk &B, const FoldDev &F, const BmWork &W, int K, double lambda, double alpha,
+                GmScalars &S, double *loglik)
+{
+    S.status = 0; S.M = 2; S.beta = 0; S.b = 0;
+    CNT(c = FitCounters{});
+    PAR(i, W.ld) W.A[i] = 0;                                   // Calloc'd per fit, never cleared after (Q12)
+    blk_sync(B);
+    double vk = 1e-30, vk0, err = 1000, ll = 0;
+    int iter = 0;
+    while (iter < 100 && err > 1e-8) {
+        iter++;
+        vk0 = vk;
+        if (bm_inner(B, F, W, K, lambda, alpha, S, iter, &ll)) break;
+        double ap = 0;
+        PAR(i, S.M) ap += fabs(W.A[i]);                        // dasum over M = N_used + 1 entries
+        vk = blk_sum(B, ap);
+        err = fabs(vk - vk0) / S.M;
+    }
+    *loglik = ll;
+    CNT(c.n_outer = iter; c.m_final = S.M - 1; c.status = S.status);
+    blk_sync(B);
+}
+
+// fold score, R/GetModelError.R:34-57: mean Bernoulli log-likelihood of the held-out rows
+DEV double bm_fold_loglik(const Blk &B, const FoldDev &F, const BmWork &W, const GmScalars &S)
+{
+    const int nte = F.nte, M = S.M;
+    // eta -> exp(eta), with R's clamp applied only when max/min cross the thresholds
+    double mx = -1e300, mn = 1e300;
+    int any = 0;
+    for (int j = 1; j < M; j++) if (W.mu[j] / F.scale[W.used[j - 1]] != 0) any = 1;
+    if (!any) return 0.0;                                      // null model: logL <- 0 (:42-43)
+    PAR(h, nte) {
+        double eta = 0;
+        for (int j = 1; j < M; j++) { const int u = W.used[j - 1]; eta += F.Xte[(size_t)u * nte + h] * (W.mu[j] / F.scale[u]); }
+        const double t = exp(W.mu[0] + eta);
+        W.pm[h] = t;
+        if (t > mx) mx = t;
+        if (t < mn) mn = t;
+    }
+    double dummy; int di;
+    blk_argmax(B, mx, 0, &mx, &di);
+    blk_argmax(B, -mn, 0, &dummy, &di); mn = -dummy;
+    blk_sync(B);
+    double part = 0;
+    PAR(h, nte) {
+        double t = W.pm[h];
+        if (mx > 1e10 && t > 1e10) t = 1e5;
+        if (mn < 1e-10 && t < 1e-10) t = 1e-5;
+        part += F.yte[h] * log(t / (1 + t)) + (1 - F.yte[h]) * log(1 / (1 + t));
+    }
+    return blk_sum(B, part) / nte;
+}

@@ -23,6 +23,7 @@
 #include "types.h"
 #include "blk.h"
 #include "gm_fit.h"
+#include "bm_fit.h"
 
 // ------------------------------------------------------------------------------------------
 // error plumbing
@@ -208,6 +209,46 @@ __device__ inline GmWork ws_carve(char *base, int K, int cap, size_t offK, size_
     return W;
 }
 
+// binomial workspace: K-vectors, (ld x ld) Sigma and H, ld-vectors, N-vectors, K x ld weighted rows
+struct BmLayout { size_t bytes; int cap, ld, nmax; size_t offK, offSig, offM, offN, offBP; };
+
+static BmLayout bm_layout(int K, int nmax)
+{
+    BmLayout L;
+    int cap = K + 1; if (cap > 1024) cap = 1024;
+    L.cap = cap; L.ld = cap + 1; L.nmax = nmax;
+    size_t o = 0;
+    L.offK = o;   o += align_up((size_t)K * (7 * sizeof(double) + 2 * sizeof(int) + 1), 256);
+    L.offSig = o; o += align_up((size_t)2 * L.ld * L.ld * sizeof(double), 256);
+    L.offM = o;   o += align_up((size_t)L.ld * (9 * sizeof(double) + sizeof(int)), 256);
+    L.offN = o;   o += align_up((size_t)nmax * 5 * sizeof(double), 256);
+    L.offBP = o;  o += align_up((size_t)K * L.ld * sizeof(double), 256);
+    L.bytes = align_up(o, 4096);
+    return L;
+}
+
+__device__ inline BmWork bm_carve(char *base, int K, const BmLayout &L)
+{
+    BmWork W;
+    double *d = (double *)(base + L.offK);
+    W.Sin = d; d += K; W.Qin = d; d += K; W.Sout = d; d += K; W.Qout = d; d += K;
+    W.dml = d; d += K; W.aroot = d; d += K; W.bb = d; d += K;
+    int *ip = (int *)d;
+    W.upos = ip; ip += K; W.todo = ip; ip += K;
+    W.act = (signed char *)ip;
+    d = (double *)(base + L.offSig);
+    W.Sig = d; d += (size_t)L.ld * L.ld; W.H = d;
+    d = (double *)(base + L.offM);
+    W.A = d; d += L.ld; W.mu = d; d += L.ld; W.g = d; d += L.ld; W.dmu = d; d += L.ld; W.mnew = d; d += L.ld;
+    W.tmp = d; d += L.ld; W.tp = d; d += L.ld; W.v3 = d; d += L.ld; W.v4 = d; d += L.ld;
+    W.used = (int *)d;
+    d = (double *)(base + L.offN);
+    W.w = d; d += L.nmax; W.pm = d; d += L.nmax; W.yv = d; d += L.nmax; W.e = d; d += L.nmax; W.bphi = d;
+    W.BP = (double *)(base + L.offBP);
+    W.cap = L.cap; W.ld = L.ld;
+    return W;
+}
+
 // ------------------------------------------------------------------------------------------
 // fit kernels
 
@@ -297,6 +338,48 @@ __global__ __launch_bounds__(FIT_THREADS) void gm_cv_kernel(CvParams P)
     }
 }
 
+struct BmCvParams {
+    const FoldDev *folds;
+    const double *alpha, *lambda;
+    const int *order;
+    int *queue;
+    double *fold_err;
+    int *status;
+    long long *counters;
+    char *ws;
+    BmLayout L;
+    int K, n_folds, n_units;
+};
+
+__global__ __launch_bounds__(FIT_THREADS) void bm_cv_kernel(BmCvParams P)
+{
+    __shared__ int s_unit;
+    __shared__ FitCounters s_cnt;
+    __shared__ long long s_ph[8];
+    const Blk B = make_blk();
+    const BmWork W = bm_carve(P.ws + (size_t)blockIdx.x * P.L.bytes, P.K, P.L);
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_unit = atomicAdd(P.queue, 1);
+        __syncthreads();
+        const int q = s_unit;
+        if (q >= P.n_units) break;
+        const int unit = P.order[q];
+        const int cell = unit / P.n_folds, f = unit % P.n_folds;
+        const FoldDev F = P.folds[f];
+        GmScalars S;
+        S.c = &s_cnt; S.ph = s_ph;
+        double ll;
+        bm_fit(B, F, W, P.K, P.lambda[cell], P.alpha[cell], S, &ll);
+        const double score = bm_fold_loglik(B, F, W, S);
+        if (threadIdx.x == 0) {
+            P.fold_err[unit] = score;
+            P.status[unit] = S.status;
+            if (P.counters) store_counters(P.counters + (size_t)unit * PAREBEN_NCOUNTERS, s_cnt);
+        }
+    }
+}
+
 struct FitParams {
     FoldDev F;
     double lambda, alpha;
@@ -366,6 +449,7 @@ struct pareben_ctx {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     char *d_ws = nullptr; size_t ws_bytes = 0; int ws_blocks = 0;
     WsLayout L{};
+    BmLayout BL{};
     double last_ms[3] = {0, 0, 0};
     int64_t launch_info[4] = {0, 0, 0, 0};
     int n_cu = 0;
@@ -439,7 +523,7 @@ static int ctx_create_impl(pareben_ctx **out, int device, const double *basis, i
         CK(dmalloc(&H.Xte, (size_t)H.nte * p)); CK(dmalloc(&H.yte, (size_t)H.nte));
         CK(dmalloc(&H.scale, (size_t)p)); CK(dmalloc(&H.rscale, (size_t)p));
         CK(dmalloc(&H.bt0, (size_t)p)); CK(dmalloc(&H.cs, (size_t)p));
-        CK(dmalloc(&H.G, (size_t)p * p));
+        if (prior == PAREBEN_PRIOR_GAUSSIAN) CK(dmalloc(&H.G, (size_t)p * p));   // binomial: no Gram matrix (weights change)
         CK(dmalloc(&H.ystat, (size_t)2));
         FoldDev &D = fd[f];
         D.X = H.X; D.y = H.y; D.Xte = H.Xte; D.yte = H.yte; D.scale = H.scale; D.rscale = H.rscale;
@@ -457,8 +541,8 @@ extern "C" int pareben_ctx_create(pareben_ctx **out, int device, const double *b
                                   int prior, int epis, int max_active)
 {
     if (!out || !basis || !target || !fold_id || n < 2 || p < 1 || n_folds < 1) return fail(PAREBEN_EINVAL, "bad argument");
-    if (prior != PAREBEN_PRIOR_GAUSSIAN || epis != 0)
-        return fail(PAREBEN_EUNSUPPORTED, "only prior=gaussian, epis=0 is built in this version");
+    if ((prior != PAREBEN_PRIOR_GAUSSIAN && prior != PAREBEN_PRIOR_BINOMIAL) || epis != 0)
+        return fail(PAREBEN_EUNSUPPORTED, "epistasis (epis=1) is not built in this version");
     for (int i = 0; i < n; i++) if (fold_id[i] < 1 || fold_id[i] > n_folds) return fail(PAREBEN_EINVAL, "fold_id out of 1..n_folds");
     std::vector<std::vector<int>> tr(n_folds), te(n_folds);
     for (int f = 0; f < n_folds; f++)
@@ -478,8 +562,10 @@ static int prepare_folds(pareben_ctx *c)
         if (H.nte) hipLaunchKernelGGL(gather_kernel, dim3((H.nte + 255) / 256), dim3(256), 0, c->stream, c->d_y, H.d_te, H.nte, H.yte);
         hipLaunchKernelGGL(colstats_kernel, dim3(p), dim3(256), 0, c->stream, H.X, H.y, H.N, H.scale, H.rscale, H.bt0, H.cs);
         hipLaunchKernelGGL(ystats_kernel, dim3(1), dim3(256), 0, c->stream, H.y, H.N, H.ystat);
-        dim3 gg((p + GT - 1) / GT, (p + GT - 1) / GT);
-        hipLaunchKernelGGL(gram_kernel, gg, dim3(256), 0, c->stream, H.X, H.N, p, H.scale, H.rscale, H.G);
+        if (H.G) {
+            dim3 gg((p + GT - 1) / GT, (p + GT - 1) / GT);
+            hipLaunchKernelGGL(gram_kernel, gg, dim3(256), 0, c->stream, H.X, H.N, p, H.scale, H.rscale, H.G);
+        }
         // ymean / varY live inside the FoldDev record: copy the two doubles device-to-device
         HIPCHK(hipMemcpyAsync((char *)(c->d_folds + f) + offsetof(FoldDev, ymean), H.ystat, 2 * sizeof(double),
                               hipMemcpyDeviceToDevice, c->stream));
@@ -491,7 +577,14 @@ static int prepare_folds(pareben_ctx *c)
 static int ensure_workspace(pareben_ctx *c, int blocks)
 {
     c->L = ws_layout(c->p, c->cap);
-    const size_t need = c->L.bytes * (size_t)blocks;
+    size_t per = c->L.bytes;
+    if (c->prior == PAREBEN_PRIOR_BINOMIAL) {
+        int nmax = 1;
+        for (auto &f : c->folds) nmax = std::max(nmax, std::max(f.N, f.nte));
+        c->BL = bm_layout(c->p, nmax);
+        per = c->BL.bytes;
+    }
+    const size_t need = per * (size_t)blocks;
     if (need > c->ws_bytes) {
         if (c->d_ws) { hipFree(c->d_ws); c->d_ws = nullptr; c->ws_bytes = 0; }
         hipError_t e = hipMalloc((void **)&c->d_ws, need);
@@ -523,8 +616,14 @@ extern "C" int pareben_ctx_run(pareben_ctx *c, int n_cells, const double *alpha,
     for (int k = 0; k < n_cells; k++) for (int f = 0; f < nF; f++) order[k * nF + f] = cells[k] * nF + f;
 
     int occ = 1;
-    HIPCHK(hipFuncSetAttribute((const void *)gm_cv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FIT_BYTES));
-    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, gm_cv_kernel, FIT_THREADS, LDS_FIT_BYTES));
+    const bool binom = c->prior == PAREBEN_PRIOR_BINOMIAL;
+    if (binom) {
+        HIPCHK(hipFuncSetAttribute((const void *)bm_cv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FIT_BYTES));
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, bm_cv_kernel, FIT_THREADS, LDS_FIT_BYTES));
+    } else {
+        HIPCHK(hipFuncSetAttribute((const void *)gm_cv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FIT_BYTES));
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, gm_cv_kernel, FIT_THREADS, LDS_FIT_BYTES));
+    }
     if (occ < 1) occ = 1;
     int blocks = std::min(n_units, c->n_cu * occ);
     int rc = ensure_workspace(c, blocks);
@@ -562,7 +661,15 @@ extern "C" int pareben_ctx_run(pareben_ctx *c, int n_cells, const double *alpha,
     P.fold_err = d_err; P.status = d_status; P.counters = d_cnt; P.phase = d_phase; P.ws = c->d_ws;
     P.ws_stride = c->L.bytes; P.offK = c->L.offK; P.offSig = c->L.offSig; P.offM = c->L.offM;
     P.K = c->p; P.cap = c->cap; P.n_folds = nF; P.n_units = n_units;
-    hipLaunchKernelGGL(gm_cv_kernel, dim3(blocks), dim3(FIT_THREADS), LDS_FIT_BYTES, c->stream, P);
+    if (binom) {
+        BmCvParams Q;
+        Q.folds = c->d_folds; Q.alpha = d_alpha; Q.lambda = d_lambda; Q.order = d_order; Q.queue = d_queue;
+        Q.fold_err = d_err; Q.status = d_status; Q.counters = d_cnt; Q.ws = c->d_ws; Q.L = c->BL;
+        Q.K = c->p; Q.n_folds = nF; Q.n_units = n_units;
+        hipLaunchKernelGGL(bm_cv_kernel, dim3(blocks), dim3(FIT_THREADS), LDS_FIT_BYTES, c->stream, Q);
+    } else {
+        hipLaunchKernelGGL(gm_cv_kernel, dim3(blocks), dim3(FIT_THREADS), LDS_FIT_BYTES, c->stream, P);
+    }
     CK(hipGetLastError());
     CK(hipEventRecord(c->ev[2], c->stream));
 
@@ -584,7 +691,8 @@ extern "C" int pareben_ctx_run(pareben_ctx *c, int n_cells, const double *alpha,
     CK(hipEventElapsedTime(&t, c->ev[0], c->ev[3]));
     c->last_ms[0] = a; c->last_ms[1] = b; c->last_ms[2] = t;
     c->launch_info[0] = blocks; c->launch_info[1] = FIT_THREADS; c->launch_info[2] = c->cap;
-    c->launch_info[3] = (int64_t)(c->L.bytes >> 10);
+    c->launch_info[2] = binom ? c->BL.cap : c->cap;
+    c->launch_info[3] = (int64_t)((binom ? c->BL.bytes : c->L.bytes) >> 10);
 #undef CK
     cleanup();
     return PAREBEN_OK;

@@ -25,6 +25,7 @@ def golden():
         yBinomial = np.load(os.path.join(GOLDEN, "yBinomial.npy")).astype(np.float64)
         config1 = np.load(os.path.join(GOLDEN, "config1_gm.npz"))
         basis481 = np.load(os.path.join(GOLDEN, "basis481_gm.npz"))
+        config3 = np.load(os.path.join(GOLDEN, "config3_bm.npz"))
         rds = np.load(os.path.join(GOLDEN, "rds_10000.npz"))
         import json
         known = json.load(open(os.path.join(GOLDEN, "survey_known_answers.json")))

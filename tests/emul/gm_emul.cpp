@@ -7,9 +7,11 @@
 #include <cmath>
 #include <cstring>
 #include <cstdlib>
+#include <algorithm>
 #include "../../pareben_amd/csrc/types.h"
 #include "../../pareben_amd/csrc/blk.h"
 #include "../../pareben_amd/csrc/gm_fit.h"
+#include "../../pareben_amd/csrc/bm_fit.h"
 
 namespace {
 struct Fold {
@@ -126,4 +128,43 @@ extern "C" int emul_gm_fit(const double *X, const double *y, int n, int p, doubl
     for (int i = 0; i < S.M; i++) { used[i] = ws.W.used[i]; mu[i] = ws.W.mu[i] / F.scale[ws.W.used[i]]; sigdiag[i] = ws.W.Sig[(size_t)i * cap + i] / (F.scale[ws.W.used[i]] * F.scale[ws.W.used[i]]); }
     if (counters) std::memcpy(counters, &cnt, sizeof cnt);
     return S.status;
+}
+
+
+// same contract as pareben_cv_grid (binomial, main effects): fold_err = mean held-out log-likelihood
+extern "C" int emul_bm_cv_grid(const double *basis, int n, int p, const double *y, const int *fold_id, int n_folds,
+                               const double *alpha, const double *lambda, int n_cells,
+                               double *fold_err, int *status, long long *counters)
+{
+    std::vector<Fold> folds(n_folds);
+    int nmax = 1;
+    for (int f = 0; f < n_folds; f++) { prepare(folds[f], basis, n, p, y, fold_id, f); nmax = std::max(nmax, std::max(folds[f].N, folds[f].nte)); }
+    int cap = p + 1; if (cap > 1024) cap = 1024;
+    const int ld = cap + 1;
+    std::vector<double> kd((size_t)7 * p), sig((size_t)2 * ld * ld), md((size_t)9 * ld), nd((size_t)5 * nmax), bp((size_t)p * ld);
+    std::vector<int> ki((size_t)2 * p), used(ld); std::vector<signed char> act(p);
+    BmWork W;
+    double *d = kd.data();
+    W.Sin = d; d += p; W.Qin = d; d += p; W.Sout = d; d += p; W.Qout = d; d += p; W.dml = d; d += p; W.aroot = d; d += p; W.bb = d;
+    W.upos = ki.data(); W.todo = ki.data() + p; W.act = act.data();
+    W.Sig = sig.data(); W.H = sig.data() + (size_t)ld * ld;
+    d = md.data();
+    W.A = d; d += ld; W.mu = d; d += ld; W.g = d; d += ld; W.dmu = d; d += ld; W.mnew = d; d += ld; W.tmp = d; d += ld; W.tp = d; d += ld; W.v3 = d; d += ld; W.v4 = d;
+    W.used = used.data();
+    d = nd.data();
+    W.w = d; d += nmax; W.pm = d; d += nmax; W.yv = d; d += nmax; W.e = d; d += nmax; W.bphi = d;
+    W.BP = bp.data(); W.cap = cap; W.ld = ld;
+    Blk B; B.tid = 0; B.nthr = 1; B.lane = 0; B.wave = 0; B.nwave = 1; B.red = nullptr; B.ired = nullptr; B.pool = nullptr; B.xred = nullptr; B.pool_n = 0;
+    for (int c = 0; c < n_cells; c++)
+        for (int f = 0; f < n_folds; f++) {
+            FoldDev F = dev_view(folds[f]);
+            GmScalars S; FitCounters cnt; S.c = &cnt; S.ph = nullptr;
+            double ll;
+            bm_fit(B, F, W, p, lambda[c], alpha[c], S, &ll);
+            const int u = c * n_folds + f;
+            fold_err[u] = bm_fold_loglik(B, F, W, S);
+            if (status) status[u] = S.status;
+            if (counters) std::memcpy(counters + (size_t)u * PAREBEN_NCOUNTERS, &cnt, sizeof cnt);
+        }
+    return 0;
 }

@@ -31,3 +31,13 @@ def test_basis481_subgrid(golden):
     ref = g["fold_err"][sel]
     assert (np.abs(E - ref) / np.abs(ref)).max() < 1e-10
     assert cnt[..., 10].max() > 100                  # exercises the M > 100 delete-priority regime
+
+
+def test_binomial_subgrid(golden):
+    """Binomial device source (bm_fit.h) on the CPU vs the oracle table: 5 cells x 5 folds."""
+    g = golden.config3
+    sel = [0, 101, 222, 317, 399]
+    E, st, cnt = emul_lib.cv_grid(golden.BASISbinomial, golden.yBinomial, g["fold_id"], 5, g["alpha"][sel], g["lam"][sel],
+                                  prior="binomial")
+    assert np.abs(E - g["fold_err"][sel]).max() < 1e-12
+    assert np.all(st == 0)

@@ -122,7 +122,7 @@ def test_edge_cases(oracle):
     with pytest.raises(pareben_amd.ParebenError):
         pareben_amd.Context(X, y, np.zeros(41, dtype=np.int32), 2)
     with pytest.raises(pareben_amd.ParebenError):
-        pareben_amd.Context(X, y, fid, 2, prior="binomial")
+        pareben_amd.Context(X, y, fid, 2, epis=True)
 
 
 @pytest.mark.parametrize("n,p,nf", [(1000, 2000, 5)])
@@ -149,3 +149,35 @@ def test_larger_synthetic_properties(n, p, nf, oracle):
     with pareben_amd.Context(X, y + 3.0, fid, nf) as ctx:
         Es, _, _ = ctx.run(alpha[sel][spot], lam[sel][spot])
     assert _rel(Es, E[spot]).max() < 1e-6
+
+
+def test_binomial_config3_full_grid_vs_golden(golden):
+    """BASELINE config 3: yBinomial / BASISbinomial, binomial prior, nFolds=5, 20 x 20 grid =
+    2000 fits, against the oracle table (itself equal to the survey's compiled-reference numbers)."""
+    g, k = golden.config3, golden.known["config3"]
+    out = pareben_amd.CrossValidate(golden.BASISbinomial, golden.yBinomial, nFolds=5, Epis="no", prior="binomial",
+                                    search="global", return_stats=True)
+    D = out["Results.Detail"]
+    E = np.asarray(D["logL"]).reshape(400, 5)
+    assert np.all(out["stats"]["status"] & 8 == 0)
+    assert np.abs(E - g["fold_err"]).max() < 1e-8                      # mean log-likelihoods, O(0.3)
+    assert out["alpha.optimal"] == k["alpha_opt"] and out["lambda.optimal"] == g["summary_lambda"][int(g["idx"])]
+    S = out["Results.Summary"]
+    i = int(np.argmin(np.asarray(S["Likelihood"])))
+    assert abs(np.asarray(S["Likelihood"])[i] - k["likelihood"]) < 1e-6 * k["likelihood"]
+    assert abs(np.asarray(S["SE"])[i] - k["SE"]) < 1e-6 * k["SE"]
+
+
+def test_binomial_synthetic_vs_oracle(oracle):
+    rng = np.random.default_rng(9)
+    X = np.asfortranarray(rng.standard_normal((123, 77)))
+    y = (X[:, 5] - 0.7 * X[:, 40] + 0.5 * rng.standard_normal(123) > 0).astype(float)
+    fid = AssignToFolds(X, 3)
+    alpha, lam = BuildGrid(X, y, 3)
+    sel = np.arange(0, 400, 9)
+    with pareben_amd.Context(X, y, fid, 3, prior="binomial") as ctx:
+        E, st, cnt = ctx.run(alpha[sel], lam[sel])
+    Eo, co, rc = oracle.cv_grid(X, y, fid, 3, alpha[sel], lam[sel], prior="binomial")
+    assert rc == 0 and np.all(st & 8 == 0)
+    assert np.abs(E - Eo).max() < 1e-8
+    assert cnt[..., 2].sum() == co["n_add"] and cnt[..., 3].sum() == co["n_del"]

@@ -65,3 +65,30 @@ def test_oracle_edge_cases(oracle):
     # huge lambda: nothing can be added, model stays at the initial column
     r = oracle.fit_gaussian(X, y, 1e6, 1.0)
     assert r["counters"]["m_final"] == 1 and r["counters"]["n_add"] == 0
+
+
+def test_oracle_binomial_config3(golden, oracle):
+    """Config 3 (BASISbinomial 500 x 481, yBinomial, nFolds=5): the committed full 2000-fit oracle
+    table reproduces the numbers the survey session recorded from the compiled reference C
+    (SURVEY.md section 10), and a fresh run of a sub-grid reproduces the table."""
+    g, k = golden.config3, golden.known["config3"]
+    a_s, l_s, se, lik, idx = summarise_cv(g["alpha"], g["lam"], g["fold_err"], 5, prior="binomial")
+    assert a_s[idx] == k["alpha_opt"]
+    assert abs(l_s[idx] - k["lambda_opt"]) < 1e-14 * k["lambda_opt"]       # lambda_max itself differs in the last bit
+    assert abs(lik[idx] - k["likelihood"]) < 1e-12 and abs(se[idx] - k["SE"]) < 1e-12
+    sel = [0, 57, 199, 390]
+    E, cnt, rc = oracle.cv_grid(golden.BASISbinomial, golden.yBinomial, g["fold_id"], 5, g["alpha"][sel], g["lam"][sel],
+                                prior="binomial", n_threads=4)
+    assert rc == 0 and np.array_equal(E, g["fold_err"][sel])
+    assert cnt["m_max"] - 1 <= k["max_active"]
+
+
+def test_oracle_binomial_edge_cases(oracle):
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((60, 7))
+    y = (X[:, 1] + 0.3 * rng.standard_normal(60) > 0).astype(float)
+    r = oracle.fit_binomial(X, y, 0.05, 0.5)
+    assert r["rc"] == 0 and np.isfinite(r["loglik"]) and r["loglik"] < 0
+    assert np.isfinite(r["intercept"]).all() and r["intercept"][1] > 0
+    r2 = oracle.fit_binomial(X, y, 1e6, 1.0)         # nothing can be added
+    assert r2["counters"]["n_add"] == 0

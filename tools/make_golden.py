@@ -65,6 +65,16 @@ def main():
     np.savez_compressed(OUT + "/basis481_gm.npz", alpha=aa, lam=ll, fold_id=fid5, fold_err=E5,
                         counters=np.array([cnt5[k] for k in sorted(cnt5)]), counter_names=np.array(sorted(cnt5)))
 
+    # config 3: BASISbinomial / yBinomial, binomial prior, nFolds=5, 20x20 grid (oracle, ~3 min on 8 threads)
+    Xb = Bb.astype(np.float64); ybf = yb.astype(np.float64)
+    fidb = AssignToFolds(Xb, 5)
+    ab, lb = BuildGrid(Xb, ybf, 5)
+    Eb, cntb, rc = O.cv_grid(Xb, ybf, fidb, 5, ab, lb, prior="binomial", n_threads=8)
+    assert rc == 0
+    a_s, l_s, se, err, idx = summarise_cv(ab, lb, Eb, 5, prior="binomial")
+    np.savez_compressed(OUT + "/config3_bm.npz", alpha=ab, lam=lb, fold_id=fidb, fold_err=Eb, summary_alpha=a_s,
+                        summary_lambda=l_s, summary_SE=se, summary_Likelihood=err, idx=idx)
+
     # yeast design of the stored real-R run (10000_Features): filter_matrix_looser[, 2:10001] (+-1) and
     # pheno1, bit-packed along samples (the tab-separated text is 512 MB; packed + deflated 60 kB)
     yeast_txt = os.environ.get("YEAST_MATRIX", "/tmp/work/filter_matrix_looser")   # unzip of Full_Test/filter_matrix_looser.zip
@@ -93,6 +103,9 @@ def main():
         "rng": {"runif3": [0.2655087, 0.3721239, 0.5728534],
                 "sample10": [9, 4, 7, 1, 2, 5, 3, 10, 6, 8],
                 "sample10_rounding": [3, 4, 5, 7, 2, 8, 9, 6, 10, 1]},
+        "config3": {"lambda_first": 4.901894677425395, "lambda_last": 0.004901894677425393,
+                    "alpha_opt": 0.19999999999999996, "lambda_opt": 0.014589761289879953,
+                    "likelihood": 0.3383112550401007, "SE": 0.023711752417084345, "max_active": 59},
         "yeast10000": {"lambda_max_x10": 3.156882755270842, "detail_mse_row1": 486.80072139},
     }
     with open(OUT + "/survey_known_answers.json", "w") as f:
