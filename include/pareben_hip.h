@@ -30,7 +30,7 @@ extern "C" {
 #define PAREBEN_EINVAL       -1   /* bad argument                                   */
 #define PAREBEN_EHIP         -2   /* HIP runtime error (see pareben_last_error)     */
 #define PAREBEN_ENOMEM       -3   /* device workspace does not fit                  */
-#define PAREBEN_EUNSUPPORTED -4   /* prior/epis combination not built yet           */
+#define PAREBEN_EUNSUPPORTED -4   /* binomial + epistasis is not built               */
 
 #define PAREBEN_PRIOR_GAUSSIAN 0
 #define PAREBEN_PRIOR_BINOMIAL 1
@@ -54,7 +54,9 @@ int pareben_device_count(void);
 
 /*
  * Stage one CV problem in HBM: BASIS (n x p, column-major), Target (n), fold ids (1..n_folds,
- * what R/AssignToFolds.R:6-19 returns).  epis: 0 = main effects, 1 = add pairwise columns.
+ * what R/AssignToFolds.R:6-19 returns).  prior: gaussian (elasticNetLinearNeMainEff.c /
+ * elasticNetLinearNeFull2.c) or binomial (ElasticNetBinaryNEmainEff.c).  epis: 0 = main effects,
+ * 1 = add the p(p-1)/2 pairwise columns x_i*x_j in the reference's order (gaussian only).
  * max_active <= 0 picks the default active-set capacity min(p, 1e7/p, 2048) (the reference's
  * basisMax, elasticNetLinearNeMainEff.c:68-69, bounded).  The context owns every device buffer.
  */

@@ -1,6 +1,10 @@
 /*
- * eben_gm.c -- oracle: Gaussian main-effect EBEN fit ("Gm"), a CPU restatement of the
- * algorithm in EBEN_orig/src/elasticNetLinearNeMainEff.c.
+ * eben_gm.c -- oracle: Gaussian EBEN fits, a CPU restatement of the algorithm in
+ * EBEN_orig/src/elasticNetLinearNeMainEff.c ("Gm", main effects) and, through the `variant`
+ * switches, EBEN_orig/src/elasticNetLinearNeFull2.c ("Gf", main + pairwise epistasis columns).
+ * The two reference files share their skeleton; Gf differs in a handful of constants and rules,
+ * each cited where the variant is consulted.  Gf runs on the explicitly expanded design
+ * [x_1..x_K, x_1*x_2, x_1*x_3, ..] (the reference regenerates those columns on the fly).
  *
  * TEST INFRASTRUCTURE ONLY (see eben_oracle.h).  Written from the algorithm, with its own
  * data structures (one dense row-major arena for the feature x basis cache instead of row
@@ -23,6 +27,16 @@
 enum { ACT_NONE = -10, ACT_REEST = 0, ACT_ADD = 1, ACT_DEL = -1, ACT_TERM = 10 };
 
 typedef struct {
+    int epis;              /* 0: Gm rules, 1: Gf rules                                      */
+    double n_add;          /* block cut-off factor: Gm 0.9 (:275), Gf 0.99 (Full2.c:293)    */
+    double ml_delta;       /* minimum dML: Gm 1e-3 (:277), Gf 1e-2 (Full2.c:295)            */
+    double reest_tol;      /* |dlog alpha| termination: Gm 1e-3 (:543), Gf 0.1 (Full2.c:558) */
+    double alpha_max;      /* initial precision clamp: Gm 1e2 (:995), Gf 1e3 (Full2.c:849)  */
+    double b_eps;          /* intercept denominator guard: Gm 1e-10 (:188), Gf none (Full2.c:202) */
+} gm_variant;
+
+typedef struct {
+    gm_variant v;
     int N, K, cap;
     const double *X, *y;
     double lambda, alpha;
@@ -51,12 +65,17 @@ static void gm_initialise(gm *s, int first)
         s->used[0] = 0;
         double r = 1 / s->scale[0];
         for (int h = 0; h < N; h++) s->Phi[h] = s->X[h] * r;
-        s->beta = 1 / (var_unbiased(s->t, N) * 0.01 + 1e-10);
+        if (!s->v.epis) s->beta = 1 / (var_unbiased(s->t, N) * 0.01 + 1e-10);
+        else {                                     /* Full2.c:917-921 */
+            double sd = sqrt(var_unbiased(s->t, N));
+            if (sd < 1e-6) sd = 1e-6;
+            s->beta = 1 / pow(sd * 0.1, 2);
+        }
         double p = dot_seq(N, s->Phi, s->Phi) * s->beta;
         double q = dot_seq(N, s->Phi, s->t) * s->beta;
         s->A[0] = p * p / (q * q - p);
-        if (s->A[0] < 0) s->A[0] = 1e2;
-        if (s->A[0] > 1e2) s->A[0] = 1e2;
+        if (s->A[0] < 0) s->A[0] = s->v.alpha_max;
+        if (s->A[0] > s->v.alpha_max) s->A[0] = s->v.alpha_max;
     }
     int kk = 0;
     for (int i = 0; i < K; i++) {
@@ -145,7 +164,8 @@ static int gm_delta_ml(gm *s, int *any_del, double *best, double residual, doubl
     int any_add = 0, prio_add = 0, prio_del = 0;
     *any_del = 0;
     if (M < 10) { prio_add = 1; prio_del = 0; }
-    if (M > 100 || M >= N || residual <= varY * 0.1) { prio_add = 0; prio_del = 1; }
+    if (s->v.epis ? (M > 100 || residual <= varY * 0.1)            /* Full2.c:1257 */
+                  : (M > 100 || M >= N || residual <= varY * 0.1)) { prio_add = 0; prio_del = 1; }
     for (int i = 0; i < K; i++) s->act[i] = ACT_NONE;
     double dmax = 0; int imax = 0;
 
@@ -192,7 +212,7 @@ static int gm_delta_ml(gm *s, int *any_del, double *best, double residual, doubl
                 s->aroot[f] = r + l2;
                 s->act[f] = ACT_ADD;
                 s->dml[f] = L;
-                any_add = 1;
+                if (!s->v.epis) any_add = 1;       /* Q15: only Gm sets it (:1484) */
             }
         }
         if (s->dml[f] > dmax) { imax = f; dmax = s->dml[f]; }
@@ -207,7 +227,7 @@ static int gm_delta_ml(gm *s, int *any_del, double *best, double residual, doubl
         dmax = 0; imax = 0;
         for (int i = 0; i < K; i++) if (s->dml[i] > dmax) { imax = i; dmax = s->dml[i]; }
     }
-    if ((!any_add && iter == 1 && i_iter < 10) || (!any_add && residual >= varY * 0.95)) {
+    if (!s->v.epis && ((!any_add && iter == 1 && i_iter < 10) || (!any_add && residual >= varY * 0.95))) {   /* Gm only, :1557-1577 */
         for (int i = 0; i < K; i++) if (s->act[i] == ACT_DEL) s->dml[i] = 0;
         dmax = 0; imax = 0;
         for (int i = 0; i < K; i++) if (s->dml[i] > dmax) { imax = i; dmax = s->dml[i]; }
@@ -386,8 +406,8 @@ static int gm_inner(gm *s, int iter, double residual, double varY, double *cs, d
             sel = ACT_DEL;
         } else {
             worthwhile = 1;
-            double cutoff = best * (s->act[nu] == ACT_ADD ? 0.9 : 1.0);
-            if (cutoff < 0.001) cutoff = 0.001;
+            double cutoff = best * (s->act[nu] == ACT_ADD ? s->v.n_add : 1.0);
+            if (cutoff < s->v.ml_delta) cutoff = s->v.ml_delta;
             n_todo = 0;
             for (int i = 0; i < K; i++) if (s->dml[i] >= cutoff) s->todo[n_todo++] = i;
             if (s->act[nu] == ACT_DEL && n_todo > 1) n_todo = 1;
@@ -409,7 +429,7 @@ static int gm_inner(gm *s, int iter, double residual, double varY, double *cs, d
                 }
                 double r = 1 / s->scale[nu];
                 for (int h = 0; h < N; h++) phi[h] = s->X[(size_t)nu * N + h] * r;
-                if (sel == ACT_REEST && fabs(log(newA) - log(s->A[jj])) <= 1e-3 && any_del == 0)
+                if (sel == ACT_REEST && fabs(log(newA) - log(s->A[jj])) <= s->v.reest_tol && any_del == 0)
                     sel = ACT_TERM;
                 int upd = 0;
                 if (sel == ACT_REEST) {
@@ -478,23 +498,19 @@ static int gm_inner(gm *s, int iter, double residual, double varY, double *cs, d
     return 0;
 }
 
-int eben_gm_fit(const double *X, const double *y, int N, int K, double lambda, double alpha,
-                double *Beta, double *wald, double *intercept, double *residual,
-                eben_counters *cnt)
+/* shared driver: X is the (possibly expanded) N x K design; scale[] as the variant defines it.
+ * Outputs in model space: *M_out, used[], mu[]/scale and Sigma_ii/scale^2 through the callback arrays. */
+static int gm_core(const gm_variant *v, const double *X, const double *y, int N, int K, int cap, const double *scale_in,
+                   double lambda, double alpha, int *M_out, int *used_out, double *w_out, double *var_out,
+                   double *wald, double *intercept, double *residual, eben_counters *cnt)
 {
     gm S; memset(&S, 0, sizeof(S));
     gm *s = &S;
+    s->v = *v;
     s->N = N; s->K = K; s->X = X; s->y = y; s->lambda = lambda; s->alpha = alpha;
-    int cap = (int)(1e7 / K);                      /* basisMax, :68-69 */
-    if (cap > K) cap = K;
     s->cap = cap;
     s->scale = (double *)calloc(K, sizeof(double));
-    for (int i = 0; i < K; i++) {
-        Beta[i] = i + 1; Beta[K + i] = i + 1; Beta[2 * (size_t)K + i] = 0; Beta[3 * (size_t)K + i] = 0;
-        double q = dot_seq(N, X + (size_t)i * N, X + (size_t)i * N);
-        if (q == 0) q = 1;
-        s->scale[i] = sqrt(q);
-    }
+    memcpy(s->scale, scale_in, sizeof(double) * K);
     s->t = (double *)calloc(N, sizeof(double));
     s->used = (int *)calloc(cap, sizeof(int));
     s->unused = (int *)calloc(K, sizeof(int));
@@ -526,7 +542,7 @@ int eben_gm_fit(const double *X, const double *y, int N, int K, double lambda, d
         double cs, csy;
         rc = gm_inner(s, iter, residvar, varT, &cs, &csy);
         if (rc) break;
-        b = csy / (cs + 1e-10);
+        b = csy / (cs + s->v.b_eps);
         vk = 0;
         for (int i = 0; i < s->M; i++) vk += s->A[i];
         err = fabs(vk - vk0) / s->M;
@@ -536,16 +552,16 @@ int eben_gm_fit(const double *X, const double *y, int N, int K, double lambda, d
     /* Wald score uses whatever H the last final update left (its own leading dimension) */
     {
         const int M = s->M;
-        double w = 0;
         double *tw = (double *)calloc(M, sizeof(double));
         for (int i = 0; i < M; i++) tw[i] = dot_seq(M, s->mu, s->H + (size_t)i * M);
-        w = dot_seq(M, tw, s->mu);
+        *wald = dot_seq(M, tw, s->mu);
         free(tw);
-        *wald = w;
+        *M_out = M;
         for (int i = 0; i < M; i++) {
             int f = s->used[i];
-            Beta[2 * (size_t)K + f] = s->mu[i] / s->scale[f];
-            Beta[3 * (size_t)K + f] = s->Sig[(size_t)i * M + i] / (s->scale[f] * s->scale[f]);
+            used_out[i] = f;
+            w_out[i] = s->mu[i] / s->scale[f];
+            var_out[i] = s->Sig[(size_t)i * M + i] / (s->scale[f] * s->scale[f]);
         }
     }
     *intercept = b;
@@ -557,5 +573,73 @@ int eben_gm_fit(const double *X, const double *y, int N, int K, double lambda, d
     free(s->Sig); free(s->SigNew); free(s->H); free(s->Phi); free(s->BP); free(s->bt);
     free(s->Sin); free(s->Qin); free(s->Sout); free(s->Qout); free(s->dml); free(s->aroot);
     free(s->act); free(s->todo);
+    return rc;
+}
+
+int eben_gm_fit(const double *X, const double *y, int N, int K, double lambda, double alpha,
+                double *Beta, double *wald, double *intercept, double *residual,
+                eben_counters *cnt)
+{
+    const gm_variant v = {0, 0.9, 0.001, 1e-3, 1e2, 1e-10};
+    int cap = (int)(1e7 / K);                      /* basisMax, :68-69 */
+    if (cap > K) cap = K;
+    double *scale = (double *)calloc(K, sizeof(double));
+    for (int i = 0; i < K; i++) {
+        Beta[i] = i + 1; Beta[K + i] = i + 1; Beta[2 * (size_t)K + i] = 0; Beta[3 * (size_t)K + i] = 0;
+        double q = dot_seq(N, X + (size_t)i * N, X + (size_t)i * N);
+        if (q == 0) q = 1;
+        scale[i] = sqrt(q);
+    }
+    int M = 0;
+    int *used = (int *)calloc(cap + 1, sizeof(int));
+    double *w = (double *)calloc(cap + 1, sizeof(double)), *vr = (double *)calloc(cap + 1, sizeof(double));
+    int rc = gm_core(&v, X, y, N, K, cap, scale, lambda, alpha, &M, used, w, vr, wald, intercept, residual, cnt);
+    for (int i = 0; i < M; i++) { Beta[2 * (size_t)K + used[i]] = w[i]; Beta[3 * (size_t)K + used[i]] = vr[i]; }
+    free(scale); free(used); free(w); free(vr);
+    return rc;
+}
+
+/* Gaussian + epistasis, elasticNetLinearNeFull2.c:57-261.  Column order of the implicit design:
+ * K main effects, then pairs (1,2),(1,3)..(1,K),(2,3).. (:115-134). */
+int eben_gf_fit(const double *X, const double *y, int N, int K, double lambda, double alpha,
+                double *Beta, double *wald, double *intercept, double *residual,
+                eben_counters *cnt)
+{
+    const gm_variant v = {1, 0.99, 0.01, 0.1, 1e3, 0.0};
+    const size_t MF = (size_t)K * (K + 1) / 2;
+    int cap;                                       /* Full2.c:67-80 */
+    if (N > K) cap = 2 * K; else if (N < 200) cap = 4 * K; else cap = K;
+    if ((size_t)cap > MF) cap = (int)MF;
+    double *Z = (double *)malloc(sizeof(double) * (size_t)N * MF);
+    double *scale = (double *)calloc(MF, sizeof(double));
+    if (!Z || !scale) { free(Z); free(scale); return -2; }
+    memcpy(Z, X, sizeof(double) * (size_t)N * K);
+    for (int i = 0; i < K; i++) {
+        Beta[i] = i + 1; Beta[MF + i] = i + 1;
+        double q = dot_seq(N, X + (size_t)i * N, X + (size_t)i * N);
+        if (q == 0) q = 1;
+        scale[i] = sqrt(q);
+    }
+    size_t kk = K;
+    for (int i = 0; i < K - 1; i++)
+        for (int j = i + 1; j < K; j++) {
+            Beta[kk] = i + 1; Beta[MF + kk] = j + 1;
+            double q = 0;
+            const double *xi = X + (size_t)i * N, *xj = X + (size_t)j * N;
+            double *z = Z + kk * N;
+            for (int l = 0; l < N; l++) { q = q + pow(xi[l], 2) * pow(xj[l], 2); z[l] = xi[l] * xj[l]; }
+            if (q == 0) q = 1;
+            scale[kk] = sqrt(q);
+            kk++;
+        }
+    for (size_t e = 0; e < MF; e++) { Beta[2 * MF + e] = 0; Beta[3 * MF + e] = 0; Beta[4 * MF + e] = 0; }
+    int M = 0;
+    int *used = (int *)calloc(cap + 1, sizeof(int));
+    double *w = (double *)calloc(cap + 1, sizeof(double)), *vr = (double *)calloc(cap + 1, sizeof(double));
+    int rc = gm_core(&v, Z, y, N, (int)MF, cap, scale, lambda, alpha, &M, used, w, vr, wald, intercept, residual, cnt);
+    for (int i = 0; i < M; i++) {
+        Beta[2 * MF + used[i]] = w[i]; Beta[3 * MF + used[i]] = vr[i]; Beta[4 * MF + used[i]] = used[i] + 1;   /* :232-238 */
+    }
+    free(Z); free(scale); free(used); free(w); free(vr);
     return rc;
 }

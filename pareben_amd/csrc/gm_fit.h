@@ -47,6 +47,7 @@ enum { UP_FREE = -1, UP_LOST = -2 };
 enum { PH_FS_FEAT = 0, PH_FS_REST = 1, PH_DML = 2, PH_ACTION = 3, PH_NOISE = 4, PH_INVERSE = 5, PH_FINAL_REST = 6, PH_TOTAL = 7 };
 
 struct GmScalars {
+    GmVariant v;       // main-effect / epistasis rule set
     long long *ph;     // phase ticks (LDS), diagnostic build only
     double beta;       // noise precision
     double b;          // intercept
@@ -359,12 +360,13 @@ DEV void gm_fullstat(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmS
 // feature and its value.  Ties: lowest index (the reference's first scan visits the active set
 // first; a tie across the two lists needs bit-equal dML of different action types).
 DEVNI int gm_delta_ml(const Blk &B, const GmWork &W, int K, int N, int M, double lambda, double alpha,
-                    double residual, double varY, int iter, int i_iter, int *any_del_out, double *best)
+                    double residual, double varY, int iter, int i_iter, int epis, int *any_del_out, double *best)
 {
     const double l1 = lambda * alpha, l2 = lambda * (1 - alpha);
     int prio_add = 0, prio_del = 0;
     if (M < 10) { prio_add = 1; prio_del = 0; }
-    if (M > 100 || M >= N || residual <= varY * 0.1) { prio_add = 0; prio_del = 1; }
+    if (epis ? (M > 100 || residual <= varY * 0.1)                    // Full2.c:1257
+             : (M > 100 || M >= N || residual <= varY * 0.1)) { prio_add = 0; prio_del = 1; }
     int my_add = 0, my_del = 0;
     PAR(i, K) {
         const int l = W.upos[i];
@@ -390,7 +392,7 @@ DEVNI int gm_delta_ml(const Blk &B, const GmWork &W, int K, int N, int M, double
                 } else {
                     act = ACT_ADD;
                     d_ml = L;
-                    my_add = 1;
+                    if (!epis) my_add = 1;                     // Q15: only the main-effect kernel sets it
                 }
             }
         } else if (l >= 0 && M > 1) {
@@ -416,7 +418,7 @@ DEVNI int gm_delta_ml(const Blk &B, const GmWork &W, int K, int N, int M, double
         }
         rescanned = true;
     }
-    if ((!any_add && iter == 1 && i_iter < 10) || (!any_add && residual >= varY * 0.95)) {
+    if (!epis && ((!any_add && iter == 1 && i_iter < 10) || (!any_add && residual >= varY * 0.95))) {   // :1557-1577
         PAR(i, K) if (W.act[i] == ACT_DEL) W.dml[i] = 0;
         rescanned = true;
     }
@@ -805,7 +807,12 @@ DEV int gm_inner(const Blk &B, const FoldDev &F, const GmWork &W, int K, double 
     const bool first = iter <= 1;
     if (first) {                                              // :1003-1090, Q1
         S.M = 1;
-        S.beta = 1 / (varY * 0.01 + 1e-10);
+        if (!S.v.epis) S.beta = 1 / (varY * 0.01 + 1e-10);
+        else {                                                // Full2.c:917-921
+            double sd = sqrt(varY);
+            if (sd < 1e-6) sd = 1e-6;
+            S.beta = 1 / ((sd * 0.1) * (sd * 0.1));
+        }
         PAR(i, K) W.upos[i] = UP_FREE;
         blk_sync(B);
         if (B.tid == 0) {
@@ -814,8 +821,8 @@ DEV int gm_inner(const Blk &B, const FoldDev &F, const GmWork &W, int K, double 
             const double p = F.G[0] * S.beta;
             const double q = (F.bt0[0] - S.b * F.cs[0]) * S.beta;
             double a0 = p * p / (q * q - p);
-            if (a0 < 0) a0 = 1e2;
-            if (a0 > 1e2) a0 = 1e2;
+            if (a0 < 0) a0 = S.v.alpha_max;
+            if (a0 > S.v.alpha_max) a0 = S.v.alpha_max;
             W.A[0] = a0;
         }
     } else {
@@ -836,7 +843,7 @@ DEV int gm_inner(const Blk &B, const FoldDev &F, const GmWork &W, int K, double 
         CNT(c.n_inner++);
         double best; int any_del;
         PH_BEGIN();
-        int nu = gm_delta_ml(B, W, K, N, S.M, lambda, alpha, residual, varY, iter, i_iter, &any_del, &best);
+        int nu = gm_delta_ml(B, W, K, N, S.M, lambda, alpha, residual, varY, iter, i_iter, S.v.epis, &any_del, &best);
         int worthwhile;
         if (sel == ACT_TERM && !ini_removed && S.M > 1) nu = -1;
         if (nu == -1 && ini_removed) {
@@ -852,8 +859,8 @@ DEV int gm_inner(const Blk &B, const FoldDev &F, const GmWork &W, int K, double 
         } else {
             worthwhile = 1;
             const int act_nu = W.act[nu];
-            double cutoff = best * (act_nu == ACT_ADD ? 0.9 : 1.0);
-            if (cutoff < 0.001) cutoff = 0.001;
+            double cutoff = best * (act_nu == ACT_ADD ? S.v.n_add : 1.0);
+            if (cutoff < S.v.ml_delta) cutoff = S.v.ml_delta;
             n_todo = gm_collect(B, W, K, cutoff);
             if (act_nu == ACT_DEL && n_todo > 1) n_todo = 1;
             if (n_todo == 0) worthwhile = 0;
@@ -874,7 +881,7 @@ DEV int gm_inner(const Blk &B, const FoldDev &F, const GmWork &W, int K, double 
                         if (jj < 0 || jj >= S.M) { S.status |= ST_ABORT; return 1; }
                     }
                 }
-                if (sel == ACT_REEST && fabs(log(newA) - log(W.A[jj])) <= 1e-3 && any_del == 0)
+                if (sel == ACT_REEST && fabs(log(newA) - log(W.A[jj])) <= S.v.reest_tol && any_del == 0)
                     sel = ACT_TERM;
                 blk_sync(B);
                 bool upd = false;
@@ -980,7 +987,7 @@ DEV void gm_fit(const Blk &B, const FoldDev &F, const GmWork &W, int K, double l
         vk0 = vk;
         double cs, csy;
         if (gm_inner(B, F, W, K, lambda, alpha, S, iter, residvar, varT, &cs, &csy)) break;
-        S.b = csy / (cs + 1e-10);
+        S.b = csy / (cs + S.v.b_eps);
         double a_part = 0;
         PAR(i, S.M) a_part += W.A[i];
         vk = blk_sum(B, a_part);

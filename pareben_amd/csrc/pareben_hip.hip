@@ -60,6 +60,22 @@ __global__ void split_kernel(const double *__restrict__ basis, int n, const int 
     for (int r = threadIdx.x; r < nr; r += blockDim.x) dst[r] = src[rows[r]];
 }
 
+// pairwise (epistasis) columns of one fold: Z[:, K + rank(i,j)] = x_i * x_j for i < j, in the
+// reference's order (1,2),(1,3),..,(1,K),(2,3).. (elasticNetLinearNeFull2.c:115-134); the first K
+// columns of Z are the main effects (copied by split_kernel).  One workgroup per pair column.
+__global__ void expand_kernel(const double *__restrict__ X, int N, int K, double *__restrict__ Z)
+{
+    const long long q = blockIdx.x;                       // pair rank
+    // invert rank -> (i, j): rank(i, j) = i*K - i*(i+1)/2 + (j - i - 1)
+    int i = (int)((2.0 * K - 1.0 - sqrt((2.0 * K - 1.0) * (2.0 * K - 1.0) - 8.0 * (double)q)) * 0.5);
+    while ((long long)(i + 1) * K - (long long)(i + 1) * (i + 2) / 2 <= q) i++;
+    while ((long long)i * K - (long long)i * (i + 1) / 2 > q) i--;
+    const int j = (int)(q - ((long long)i * K - (long long)i * (i + 1) / 2)) + i + 1;
+    const double *xi = X + (size_t)i * N, *xj = X + (size_t)j * N;
+    double *z = Z + ((size_t)K + q) * N;
+    for (int h = threadIdx.x; h < N; h += blockDim.x) z[h] = xi[h] * xj[h];
+}
+
 __global__ void gather_kernel(const double *__restrict__ y, const int *__restrict__ rows, int nr,
                               double *__restrict__ out)
 {
@@ -268,6 +284,7 @@ struct CvParams {
     char *ws;
     size_t ws_stride, offK, offSig, offM;
     int K, cap, n_folds, n_units;
+    GmVariant v;
 };
 
 // LDS carve of one fit workgroup (dynamic shared memory): a phase-local pool (full-stat Gram
@@ -317,6 +334,7 @@ __global__ __launch_bounds__(FIT_THREADS) void gm_cv_kernel(CvParams P)
         GmScalars S;
         S.c = &s_cnt;
         S.ph = s_ph;
+        S.v = P.v;
 #ifdef PAREBEN_PHASE_TIMERS
         if (threadIdx.x < 8) s_ph[threadIdx.x] = 0;
         __syncthreads();
@@ -404,6 +422,7 @@ __global__ __launch_bounds__(FIT_THREADS) void gm_fit_kernel(FitParams P)
     GmScalars S;
     S.c = &s_cnt;
     S.ph = s_ph;
+    S.v = GmVariant{0, 0.9, 0.001, 1e-3, 1e2, 1e-10};
     gm_fit(B, P.F, W, K, P.lambda, P.alpha, S);
     const int M = S.M, ld = W.ld;
     PAR(i, M) {
@@ -442,6 +461,8 @@ struct FoldHost {
 
 struct pareben_ctx {
     int device = 0, n = 0, p = 0, n_folds = 0, prior = 0, epis = 0, cap = 0;
+    int kfull = 0;          // columns the fit sees: p, or p(p+1)/2 with epistasis
+    GmVariant variant{};
     double *d_basis = nullptr, *d_y = nullptr;
     std::vector<FoldHost> folds;
     FoldDev *d_folds = nullptr;
@@ -498,7 +519,24 @@ static int ctx_create_impl(pareben_ctx **out, int device, const double *basis, i
     HIPCHK(hipSetDevice(device));
     pareben_ctx *c = new pareben_ctx();
     c->device = device; c->n = n; c->p = p; c->n_folds = n_folds; c->prior = prior; c->epis = epis;
-    c->cap = default_cap(p, max_active);
+    c->kfull = epis ? (int)((long long)p * (p + 1) / 2) : p;
+    if (epis && (long long)p * (p + 1) / 2 > 2000000000LL) { delete c; return fail(PAREBEN_EINVAL, "too many pairwise columns"); }
+    if (!epis) {
+        c->cap = default_cap(p, max_active);
+        c->variant = GmVariant{0, 0.9, 0.001, 1e-3, 1e2, 1e-10};
+    } else {                                       // basisMax of elasticNetLinearNeFull2.c:67-80, bounded
+        int cap = 0;
+        for (auto &tr : rows_tr) {
+            const int N = (int)tr.size();
+            const int c1 = N > p ? 2 * p : (N < 200 ? 4 * p : p);
+            cap = std::max(cap, c1);
+        }
+        if (cap > c->kfull) cap = c->kfull;
+        if (max_active > 0) cap = std::min(cap, max_active); else cap = std::min(cap, 2048);
+        c->cap = std::max(cap, 2);
+        c->variant = GmVariant{1, 0.99, 0.01, 0.1, 1e3, 0.0};
+    }
+    const size_t KF = (size_t)c->kfull;
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
     c->n_cu = prop.multiProcessorCount;
@@ -519,11 +557,11 @@ static int ctx_create_impl(pareben_ctx **out, int device, const double *basis, i
         CK(dmalloc(&H.d_tr, tr.size())); CK(dmalloc(&H.d_te, te.size()));
         CK(hipMemcpy(H.d_tr, tr.data(), sizeof(int) * tr.size(), hipMemcpyHostToDevice));
         if (!te.empty()) CK(hipMemcpy(H.d_te, te.data(), sizeof(int) * te.size(), hipMemcpyHostToDevice));
-        CK(dmalloc(&H.X, (size_t)H.N * p)); CK(dmalloc(&H.y, (size_t)H.N));
-        CK(dmalloc(&H.Xte, (size_t)H.nte * p)); CK(dmalloc(&H.yte, (size_t)H.nte));
-        CK(dmalloc(&H.scale, (size_t)p)); CK(dmalloc(&H.rscale, (size_t)p));
-        CK(dmalloc(&H.bt0, (size_t)p)); CK(dmalloc(&H.cs, (size_t)p));
-        if (prior == PAREBEN_PRIOR_GAUSSIAN) CK(dmalloc(&H.G, (size_t)p * p));   // binomial: no Gram matrix (weights change)
+        CK(dmalloc(&H.X, (size_t)H.N * KF)); CK(dmalloc(&H.y, (size_t)H.N));
+        CK(dmalloc(&H.Xte, (size_t)H.nte * KF)); CK(dmalloc(&H.yte, (size_t)H.nte));
+        CK(dmalloc(&H.scale, KF)); CK(dmalloc(&H.rscale, KF));
+        CK(dmalloc(&H.bt0, KF)); CK(dmalloc(&H.cs, KF));
+        if (prior == PAREBEN_PRIOR_GAUSSIAN) CK(dmalloc(&H.G, KF * KF));   // binomial: no Gram matrix (weights change)
         CK(dmalloc(&H.ystat, (size_t)2));
         FoldDev &D = fd[f];
         D.X = H.X; D.y = H.y; D.Xte = H.Xte; D.yte = H.yte; D.scale = H.scale; D.rscale = H.rscale;
@@ -541,8 +579,9 @@ extern "C" int pareben_ctx_create(pareben_ctx **out, int device, const double *b
                                   int prior, int epis, int max_active)
 {
     if (!out || !basis || !target || !fold_id || n < 2 || p < 1 || n_folds < 1) return fail(PAREBEN_EINVAL, "bad argument");
-    if ((prior != PAREBEN_PRIOR_GAUSSIAN && prior != PAREBEN_PRIOR_BINOMIAL) || epis != 0)
-        return fail(PAREBEN_EUNSUPPORTED, "epistasis (epis=1) is not built in this version");
+    if (prior != PAREBEN_PRIOR_GAUSSIAN && prior != PAREBEN_PRIOR_BINOMIAL) return fail(PAREBEN_EINVAL, "unknown prior");
+    if (prior == PAREBEN_PRIOR_BINOMIAL && epis != 0)
+        return fail(PAREBEN_EUNSUPPORTED, "binomial + epistasis (ElasticNetBinaryNeFull.c) is not built in this version");
     for (int i = 0; i < n; i++) if (fold_id[i] < 1 || fold_id[i] > n_folds) return fail(PAREBEN_EINVAL, "fold_id out of 1..n_folds");
     std::vector<std::vector<int>> tr(n_folds), te(n_folds);
     for (int f = 0; f < n_folds; f++)
@@ -553,18 +592,22 @@ extern "C" int pareben_ctx_create(pareben_ctx **out, int device, const double *b
 // launch the per-fold preparation on the context's stream and patch ymean/varY into d_folds
 static int prepare_folds(pareben_ctx *c)
 {
-    const int p = c->p, n = c->n;
+    const int p = c->p, n = c->n, kf = c->kfull;
     for (int f = 0; f < c->n_folds; f++) {
         FoldHost &H = c->folds[f];
         hipLaunchKernelGGL(split_kernel, dim3(p), dim3(256), 0, c->stream, c->d_basis, n, H.d_tr, H.N, H.X);
         if (H.nte) hipLaunchKernelGGL(split_kernel, dim3(p), dim3(256), 0, c->stream, c->d_basis, n, H.d_te, H.nte, H.Xte);
+        if (kf > p) {                              // pairwise columns behind the p main-effect columns
+            hipLaunchKernelGGL(expand_kernel, dim3(kf - p), dim3(256), 0, c->stream, H.X, H.N, p, H.X);
+            if (H.nte) hipLaunchKernelGGL(expand_kernel, dim3(kf - p), dim3(256), 0, c->stream, H.Xte, H.nte, p, H.Xte);
+        }
         hipLaunchKernelGGL(gather_kernel, dim3((H.N + 255) / 256), dim3(256), 0, c->stream, c->d_y, H.d_tr, H.N, H.y);
         if (H.nte) hipLaunchKernelGGL(gather_kernel, dim3((H.nte + 255) / 256), dim3(256), 0, c->stream, c->d_y, H.d_te, H.nte, H.yte);
-        hipLaunchKernelGGL(colstats_kernel, dim3(p), dim3(256), 0, c->stream, H.X, H.y, H.N, H.scale, H.rscale, H.bt0, H.cs);
+        hipLaunchKernelGGL(colstats_kernel, dim3(kf), dim3(256), 0, c->stream, H.X, H.y, H.N, H.scale, H.rscale, H.bt0, H.cs);
         hipLaunchKernelGGL(ystats_kernel, dim3(1), dim3(256), 0, c->stream, H.y, H.N, H.ystat);
         if (H.G) {
-            dim3 gg((p + GT - 1) / GT, (p + GT - 1) / GT);
-            hipLaunchKernelGGL(gram_kernel, gg, dim3(256), 0, c->stream, H.X, H.N, p, H.scale, H.rscale, H.G);
+            dim3 gg((kf + GT - 1) / GT, (kf + GT - 1) / GT);
+            hipLaunchKernelGGL(gram_kernel, gg, dim3(256), 0, c->stream, H.X, H.N, kf, H.scale, H.rscale, H.G);
         }
         // ymean / varY live inside the FoldDev record: copy the two doubles device-to-device
         HIPCHK(hipMemcpyAsync((char *)(c->d_folds + f) + offsetof(FoldDev, ymean), H.ystat, 2 * sizeof(double),
@@ -576,12 +619,12 @@ static int prepare_folds(pareben_ctx *c)
 
 static int ensure_workspace(pareben_ctx *c, int blocks)
 {
-    c->L = ws_layout(c->p, c->cap);
+    c->L = ws_layout(c->kfull, c->cap);
     size_t per = c->L.bytes;
     if (c->prior == PAREBEN_PRIOR_BINOMIAL) {
         int nmax = 1;
         for (auto &f : c->folds) nmax = std::max(nmax, std::max(f.N, f.nte));
-        c->BL = bm_layout(c->p, nmax);
+        c->BL = bm_layout(c->kfull, nmax);
         per = c->BL.bytes;
     }
     const size_t need = per * (size_t)blocks;
@@ -660,7 +703,7 @@ extern "C" int pareben_ctx_run(pareben_ctx *c, int n_cells, const double *alpha,
     P.folds = c->d_folds; P.alpha = d_alpha; P.lambda = d_lambda; P.order = d_order; P.queue = d_queue;
     P.fold_err = d_err; P.status = d_status; P.counters = d_cnt; P.phase = d_phase; P.ws = c->d_ws;
     P.ws_stride = c->L.bytes; P.offK = c->L.offK; P.offSig = c->L.offSig; P.offM = c->L.offM;
-    P.K = c->p; P.cap = c->cap; P.n_folds = nF; P.n_units = n_units;
+    P.K = c->kfull; P.cap = c->cap; P.n_folds = nF; P.n_units = n_units; P.v = c->variant;
     if (binom) {
         BmCvParams Q;
         Q.folds = c->d_folds; Q.alpha = d_alpha; Q.lambda = d_lambda; Q.order = d_order; Q.queue = d_queue;

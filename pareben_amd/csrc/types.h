@@ -20,6 +20,17 @@ struct FoldDev {
     int N, nte;
 };
 
+// The two Gaussian reference kernels share their skeleton; these are the constants and rules in
+// which elasticNetLinearNeFull2.c (epis = 1) differs from elasticNetLinearNeMainEff.c (epis = 0).
+struct GmVariant {
+    int epis;           // selects the priority / initial-beta rules
+    double n_add;       // block cut-off factor        MainEff.c:275  0.9   | Full2.c:293  0.99
+    double ml_delta;    // minimum dML                 MainEff.c:277  1e-3  | Full2.c:295  1e-2
+    double reest_tol;   // |dlog alpha| termination    MainEff.c:543  1e-3  | Full2.c:558  0.1
+    double alpha_max;   // initial precision clamp     MainEff.c:995  1e2   | Full2.c:849  1e3
+    double b_eps;       // intercept denominator guard MainEff.c:188  1e-10 | Full2.c:202  none
+};
+
 // Per-fit event counters (SURVEY.md 8(d) accounting).
 struct FitCounters {
     int64_t n_outer, n_inner, n_add, n_del, n_reest, n_fullstat;

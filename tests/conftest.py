@@ -26,6 +26,7 @@ def golden():
         config1 = np.load(os.path.join(GOLDEN, "config1_gm.npz"))
         basis481 = np.load(os.path.join(GOLDEN, "basis481_gm.npz"))
         config3 = np.load(os.path.join(GOLDEN, "config3_bm.npz"))
+        config4 = np.load(os.path.join(GOLDEN, "config4_gf.npz"))
         rds = np.load(os.path.join(GOLDEN, "rds_10000.npz"))
         import json
         known = json.load(open(os.path.join(GOLDEN, "survey_known_answers.json")))

@@ -89,12 +89,33 @@ extern "C" int emul_default_cap(int K)
     return (int)cap;
 }
 
-// same contract as pareben_cv_grid (gaussian, main effects)
-extern "C" int emul_gm_cv_grid(const double *basis, int n, int p, const double *y, const int *fold_id, int n_folds,
-                               const double *alpha, const double *lambda, int n_cells,
-                               double *fold_err, int *status, long long *counters)
+// same contract as pareben_cv_grid (gaussian; epis = 1 runs the epistasis rule set on the expanded design)
+static int emul_gauss_grid(const double *basis_in, int n, int p_in, const double *y, const int *fold_id, int n_folds,
+                           const double *alpha, const double *lambda, int n_cells, int epis,
+                           double *fold_err, int *status, long long *counters)
 {
-    const int cap = emul_default_cap(p);
+    std::vector<double> Z;
+    const double *basis = basis_in;
+    int p = p_in;
+    GmVariant variant{0, 0.9, 0.001, 1e-3, 1e2, 1e-10};
+    int cap = emul_default_cap(p);
+    if (epis) {                                    // expanded design, reference column order
+        p = p_in * (p_in + 1) / 2;
+        Z.resize((size_t)n * p);
+        std::memcpy(Z.data(), basis_in, sizeof(double) * (size_t)n * p_in);
+        size_t kk = p_in;
+        for (int i = 0; i < p_in - 1; i++)
+            for (int j = i + 1; j < p_in; j++, kk++)
+                for (int h = 0; h < n; h++) Z[kk * n + h] = basis_in[(size_t)i * n + h] * basis_in[(size_t)j * n + h];
+        basis = Z.data();
+        variant = GmVariant{1, 0.99, 0.01, 0.1, 1e3, 0.0};
+        cap = 0;
+        for (int f = 0; f < n_folds; f++) {
+            int N = 0; for (int i = 0; i < n; i++) if (fold_id[i] != f + 1) N++;
+            cap = std::max(cap, N > p_in ? 2 * p_in : (N < 200 ? 4 * p_in : p_in));
+        }
+        cap = std::min(std::min(cap, p), 2048);
+    }
     std::vector<Fold> folds(n_folds);
     for (int f = 0; f < n_folds; f++) prepare(folds[f], basis, n, p, y, fold_id, f);
     Work ws(p, cap);
@@ -102,7 +123,7 @@ extern "C" int emul_gm_cv_grid(const double *basis, int n, int p, const double *
     for (int c = 0; c < n_cells; c++)
         for (int f = 0; f < n_folds; f++) {
             FoldDev F = dev_view(folds[f]);
-            GmScalars S; FitCounters cnt; S.c = &cnt; S.ph = nullptr;
+            GmScalars S; FitCounters cnt; S.c = &cnt; S.ph = nullptr; S.v = variant;
             gm_fit(B, F, ws.W, p, lambda[c], alpha[c], S);
             const int u = c * n_folds + f;
             fold_err[u] = gm_fold_sse(B, F, ws.W, S);
@@ -111,6 +132,16 @@ extern "C" int emul_gm_cv_grid(const double *basis, int n, int p, const double *
         }
     return 0;
 }
+
+extern "C" int emul_gm_cv_grid(const double *basis, int n, int p, const double *y, const int *fold_id, int n_folds,
+                               const double *alpha, const double *lambda, int n_cells,
+                               double *fold_err, int *status, long long *counters)
+{ return emul_gauss_grid(basis, n, p, y, fold_id, n_folds, alpha, lambda, n_cells, 0, fold_err, status, counters); }
+
+extern "C" int emul_gf_cv_grid(const double *basis, int n, int p, const double *y, const int *fold_id, int n_folds,
+                               const double *alpha, const double *lambda, int n_cells,
+                               double *fold_err, int *status, long long *counters)
+{ return emul_gauss_grid(basis, n, p, y, fold_id, n_folds, alpha, lambda, n_cells, 1, fold_err, status, counters); }
 
 // one fit on all rows; out = {intercept, beta(noise precision), M}; used/mu sized >= cap
 extern "C" int emul_gm_fit(const double *X, const double *y, int n, int p, double lambda, double alpha,
@@ -122,7 +153,7 @@ extern "C" int emul_gm_fit(const double *X, const double *y, int n, int p, doubl
     Work ws(p, cap);
     Blk B; B.tid = 0; B.nthr = 1; B.lane = 0; B.wave = 0; B.nwave = 1; B.red = nullptr; B.ired = nullptr; B.pool = nullptr; B.xred = nullptr; B.pool_n = 0;
     FoldDev D = dev_view(F);
-    GmScalars S; FitCounters cnt; S.c = &cnt; S.ph = nullptr;
+    GmScalars S; FitCounters cnt; S.c = &cnt; S.ph = nullptr; S.v = GmVariant{0, 0.9, 0.001, 1e-3, 1e2, 1e-10};
     gm_fit(B, D, ws.W, p, lambda, alpha, S);
     out[0] = S.b; out[1] = S.beta; out[2] = S.M;
     for (int i = 0; i < S.M; i++) { used[i] = ws.W.used[i]; mu[i] = ws.W.mu[i] / F.scale[ws.W.used[i]]; sigdiag[i] = ws.W.Sig[(size_t)i * cap + i] / (F.scale[ws.W.used[i]] * F.scale[ws.W.used[i]]); }

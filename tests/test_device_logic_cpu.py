@@ -41,3 +41,18 @@ def test_binomial_subgrid(golden):
                                   prior="binomial")
     assert np.abs(E - g["fold_err"][sel]).max() < 1e-12
     assert np.all(st == 0)
+
+
+def test_epistasis_subgrid(golden):
+    """Epistasis rule set (GmVariant epis=1) of the device source on the CPU vs the oracle."""
+    g = golden.config4
+    X = golden.BASIS[:200, :60]
+    sel = [0, 7, 13, 20]
+    E, st, cnt = emul_lib.cv_grid(X, g["y_scaled"], g["fold_id"], 5, g["alpha_scaled"][sel], g["lam_scaled"][sel], epis=True)
+    ref = g["fold_err_scaled"][sel]
+    ok = (st & 8) == 0
+    assert ok.sum() >= 15
+    assert (np.abs(E - ref) / ref)[ok].max() < 1e-10
+    sel2 = [0, 399]
+    E2, st2, _ = emul_lib.cv_grid(X, golden.y[:200], g["fold_id"], 5, g["alpha"][sel2], g["lam"][sel2], epis=True)
+    assert (np.abs(E2 - g["fold_err"][sel2]) / g["fold_err"][sel2]).max() < 1e-10

@@ -122,7 +122,7 @@ def test_edge_cases(oracle):
     with pytest.raises(pareben_amd.ParebenError):
         pareben_amd.Context(X, y, np.zeros(41, dtype=np.int32), 2)
     with pytest.raises(pareben_amd.ParebenError):
-        pareben_amd.Context(X, y, fid, 2, epis=True)
+        pareben_amd.Context(X, y, fid, 2, prior="binomial", epis=True)   # Bf (binomial + epistasis) is not built
 
 
 @pytest.mark.parametrize("n,p,nf", [(1000, 2000, 5)])
@@ -181,3 +181,23 @@ def test_binomial_synthetic_vs_oracle(oracle):
     assert rc == 0 and np.all(st & 8 == 0)
     assert np.abs(E - Eo).max() < 1e-8
     assert cnt[..., 2].sum() == co["n_add"] and cnt[..., 3].sum() == co["n_del"]
+
+
+def test_epistasis_vs_golden(golden):
+    """BASELINE config-4 shape at the size the oracle sweeps in seconds: Epis="yes" on
+    BASIS[1:200,1:60] (1830 implicit columns), the reference's own grid (2000 fits, Q9: all <= 1
+    feature) and a sub-grid on the normalised target with active sets up to ~100."""
+    X, y = golden.BASIS[:200, :60], golden.y[:200]
+    g, k = golden.config4, golden.known["gf_basis200x60"]
+    out = pareben_amd.CrossValidate(X, y, nFolds=5, Epis="yes", prior="gaussian", search="global", return_stats=True)
+    E = np.asarray(out["Results.Detail"]["MSE"]).reshape(400, 5)
+    assert _rel(E, g["fold_err"]).max() < REL_FOLD
+    assert out["alpha.optimal"] == k["alpha_opt"] and out["lambda.optimal"] == k["lambda_opt"]
+    S = out["Results.Summary"]
+    assert abs(np.min(np.asarray(S["MSE"])) - k["cv_error"]) < REL_CV * k["cv_error"]
+    with pareben_amd.Context(X, g["y_scaled"], g["fold_id"], 5, epis=True) as ctx:
+        E2, st, cnt = ctx.run(g["alpha_scaled"], g["lam_scaled"])
+    ok = (st & 8) == 0                                # capacity aborts mirror the oracle's (reference: heap overflow)
+    ref = g["fold_err_scaled"]
+    assert ok.mean() > 0.7
+    assert _rel(E2[ok], ref[ok]).max() < 1e-8

@@ -92,3 +92,26 @@ def test_oracle_binomial_edge_cases(oracle):
     assert np.isfinite(r["intercept"]).all() and r["intercept"][1] > 0
     r2 = oracle.fit_binomial(X, y, 1e6, 1.0)         # nothing can be added
     assert r2["counters"]["n_add"] == 0
+
+
+def test_oracle_epistasis_known_answers(golden, oracle):
+    """Gf on BASIS[1:200,1:60], Epis="yes", nFolds=5 (2000 fits): lambda_max, (alpha*, lambda*) and
+    cv.error recorded by the survey session from the compiled reference."""
+    from pareben_amd.grid import GetLambdaMax
+    X, y = golden.BASIS[:200, :60], golden.y[:200]
+    k, g = golden.known["gf_basis200x60"], golden.config4
+    assert GetLambdaMax(X, y, "yes") == k["lambda_max"]
+    E, cnt, rc = oracle.cv_grid(X, y, g["fold_id"], 5, g["alpha"], g["lam"], epis=True, n_threads=4)
+    assert rc == 0 and np.array_equal(E, g["fold_err"])
+    a_s, l_s, se, err, idx = summarise_cv(g["alpha"], g["lam"], E, 5)
+    assert a_s[idx] == k["alpha_opt"] and l_s[idx] == k["lambda_opt"]
+    assert abs(err[idx] - k["cv_error"]) <= 1e-12 * k["cv_error"]
+    assert cnt["m_max"] <= 2                          # Q9: every fit is a <= 1-feature model
+    # per-fit outputs: 5 columns, pair rows carry loc1 < loc2 and the 1-based column id in col 5
+    r = oracle.fit_gaussian(X, g["y_scaled"], g["lam_scaled"][10], g["alpha_scaled"][10], epis=True)
+    B = r["Beta"]
+    assert B.shape == (60 * 61 // 2, 5)
+    nz = np.nonzero(B[:, 4])[0]
+    assert len(nz) >= 1 and np.array_equal(B[nz, 4], nz + 1)
+    pairs = nz[nz >= 60]
+    assert np.all(B[pairs, 0] < B[pairs, 1])

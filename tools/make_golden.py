@@ -75,6 +75,20 @@ def main():
     np.savez_compressed(OUT + "/config3_bm.npz", alpha=ab, lam=lb, fold_id=fidb, fold_err=Eb, summary_alpha=a_s,
                         summary_lambda=l_s, summary_SE=se, summary_Likelihood=err, idx=idx)
 
+    # config-4 style epistasis case: BASIS[1:200,1:60], Epis="yes", nFolds=5 -- the reference's own
+    # (near-degenerate) grid, plus a sub-grid on the normalised target where fits are non-trivial
+    Xe, ye = Bf[:200, :60], y[:200]
+    fide = AssignToFolds(Xe, 5)
+    ae, le = BuildGrid(Xe, ye, 5, "yes")
+    Ee, _, rc = O.cv_grid(Xe, ye, fide, 5, ae, le, epis=True, n_threads=8)
+    assert rc == 0
+    ys = (ye - ye.mean()) / np.linalg.norm(ye - ye.mean())
+    a2, l2 = BuildGrid(Xe, ys, 5, "yes")
+    sel = np.arange(3, 400, 19)
+    E2, _, rc2 = O.cv_grid(Xe, ys, fide, 5, a2[sel], l2[sel], epis=True, n_threads=8)
+    np.savez_compressed(OUT + "/config4_gf.npz", alpha=ae, lam=le, fold_id=fide, fold_err=Ee, alpha_scaled=a2[sel],
+                        lam_scaled=l2[sel], fold_err_scaled=E2, y_scaled=ys)
+
     # yeast design of the stored real-R run (10000_Features): filter_matrix_looser[, 2:10001] (+-1) and
     # pheno1, bit-packed along samples (the tab-separated text is 512 MB; packed + deflated 60 kB)
     yeast_txt = os.environ.get("YEAST_MATRIX", "/tmp/work/filter_matrix_looser")   # unzip of Full_Test/filter_matrix_looser.zip
@@ -106,6 +120,8 @@ def main():
         "config3": {"lambda_first": 4.901894677425395, "lambda_last": 0.004901894677425393,
                     "alpha_opt": 0.19999999999999996, "lambda_opt": 0.014589761289879953,
                     "likelihood": 0.3383112550401007, "SE": 0.023711752417084345, "max_active": 59},
+        "gf_basis200x60": {"lambda_max": 28.94863306856644, "alpha_opt": 1.0, "lambda_opt": 289.4863306856643,
+                           "cv_error": 4684.6559987079645},
         "yeast10000": {"lambda_max_x10": 3.156882755270842, "detail_mse_row1": 486.80072139},
     }
     with open(OUT + "/survey_known_answers.json", "w") as f:
