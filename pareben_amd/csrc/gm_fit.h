@@ -98,82 +98,72 @@ template <class T> DEV T *uni_ptr(T *p)
     return (T *)(((unsigned long long)hi << 32) | lo);
 }
 #define FS_JTW 2          // row tiles per wave and pass (each against 4 feature sub-tiles)
-#define FS_PC 32          // Gram rows staged per chunk
+#define FS_PC 16          // Gram rows staged per chunk (= one k-block)
 #define FS_LD 80          // LDS row pitch in doubles (64 + 16: conflict-free b64 reads)
 #define FS_SR 4           // staged rows per wave and chunk (FS_PC / 8 waves at least)
 #define FS_PF 4           // Sigma-operand prefetch distance in k-steps (divides FS_PC / 4)
+#ifndef FS_NWAVES
+#define FS_NWAVES 16      // wavefronts per fit workgroup (set by the kernel file from FIT_THREADS)
+#endif
 
-// All k-steps of one pass for the NT (<= 2) row tiles of this wave against the four 16-feature
-// sub-tiles of the staged Gram tile: per k-step NT Sigma-operand loads feed 4*NT MFMAs.
-//   * Sigma lives beyond L2 (every workgroup owns a different one): its operands are prefetched
-//     FS_PF k-steps ahead through a register ring that runs across the LDS chunk boundaries.
-//   * Sigma is symmetric: row tile J only visits the k-blocks P <= J; the strictly-lower blocks
-//     count twice (acc *= 2 when the diagonal block is reached), which halves the matrix work.
-//   * the Gram rows of chunk c+1 are fetched into registers at the start of chunk c and written
-//     to LDS after its MFMAs.
-template <int NT>
-DEV void fs_pass(gptr_cd Sig, gptr_cd G, lptr_i lused, lptr_d lt, int ld, int row_max, const int *roff,
-                 int M, int K, int n_chunk, int istage, int wave, int lane, int NW, const int *kdiag,
-                 d4 (*acc)[4])
+// One 16-row k-block (4 k-steps) for the row tiles in MASK (bit 0: tile 0, bit 1: tile 1) against the
+// four 16-feature sub-tiles of the staged Gram block.  Everything that comes from beyond L2 is
+// fetched TWO k-blocks ahead into registers: the Sigma operands of block h+2 (ring a_cur -> a_nx1 ->
+// a_nx2) and the Gram rows of block h+2 (sv_nx1 -> sv_nx2; block h+1's rows are written to LDS at the
+// end of this block).  Straight-line on purpose: no branch separates a load from its use, so the
+// compiler keeps counted s_waitcnt vmcnt(N) and the prefetches overlap two blocks of MFMAs.
+//   w0 / w1: 2.0 while THIS k-block is strictly below the tile's diagonal block, 1.0 on it
+//   (Sigma is symmetric: row tile J only visits k-blocks P <= J and counts P < J twice; doubling an
+//   operand is exact).
+#define FS_RPW ((16 + FS_NWAVES - 1) / FS_NWAVES)
+template <int MASK>
+DEV void fs_kblock(gptr_cd Sig, gptr_cd G, lptr_i lused, lptr_d cur, lptr_d nxt, int ld, int row_max,
+                   int roff0, int roff1, int h, double w0, double w1, int M, int K, int istage,
+                   int wave, int lane, double (&a_cur)[4][2], double (&a_nx1)[4][2], double (&a_nx2)[4][2],
+                   double (&sv_nx1)[FS_RPW], double (&sv_nx2)[FS_RPW], d4 (&acc)[2][4])
 {
     const int l15 = lane & 15, l4 = lane >> 4;
-    const int nk = n_chunk * (FS_PC / 4);
-    double a[FS_PF][NT];
 #pragma unroll
-    for (int s = 0; s < FS_PF; s++) {
-        const int pk = s * 4 + l4;
-        const gptr_cd scol = Sig + (size_t)(pk < row_max ? pk : row_max) * ld;
-#pragma unroll
-        for (int t = 0; t < NT; t++) if (s < kdiag[t] + 4) a[s][t] = scol[roff[t]];
+    for (int r = 0; r < FS_RPW; r++) {
+        const int pp = (h + 2) * 16 + wave + r * FS_NWAVES;
+        sv_nx2[r] = G[(size_t)lused[pp < M ? pp : M - 1] * K + istage];
     }
-    double st[FS_SR];
-    for (int kk0 = 0; kk0 < nk; kk0 += FS_PF) {
+    const lptr_d brow = cur + l4 * FS_LD + l15;
 #pragma unroll
-        for (int s = 0; s < FS_PF; s++) {
-            const int kk = kk0 + s;
-            const int c = kk / (FS_PC / 4), kin = kk % (FS_PC / 4);
-            const lptr_d cur = lt + (c & 1) * (FS_PC * FS_LD);
-            if (kin == 0 && c + 1 < n_chunk) {
+    for (int s = 0; s < 4; s++) {
+        double bv[4];
 #pragma unroll
-                for (int r = 0; r < FS_SR; r++) {
-                    const int p = wave + r * NW, pp = (c + 1) * FS_PC + p;
-                    st[r] = (p < FS_PC && pp < M) ? G[(size_t)lused[pp] * K + istage] : 0.0;
-                }
-            }
-            double bv[4];
+        for (int u = 0; u < 4; u++) bv[u] = brow[s * 4 * FS_LD + u * 16];
+        if (MASK) {
+            const int pk = (h + 2) * 16 + s * 4 + l4;
+            const unsigned base = (unsigned)((pk < row_max ? pk : row_max) * ld);
+            if (MASK & 1) a_nx2[s][0] = Sig[base + roff0];
+            if (MASK & 2) a_nx2[s][1] = Sig[base + roff1];
+        }
+        if (MASK & 1) {
+            const double av = a_cur[s][0] * w0;                // doubled at use, not at load
 #pragma unroll
-            for (int u = 0; u < 4; u++) bv[u] = cur[(kin * 4 + l4) * FS_LD + u * 16 + l15];
+            for (int u = 0; u < 4; u++) acc[0][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[u], acc[0][u], 0, 0, 0);
+        }
+        if (MASK & 2) {
+            const double av = a_cur[s][1] * w1;
 #pragma unroll
-            for (int t = 0; t < NT; t++) {
-                if (kk < kdiag[t] + 4) {
-                    if (kk == kdiag[t]) {
-#pragma unroll
-                        for (int u = 0; u < 4; u++) acc[t][u] = acc[t][u] * 2.0;
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; u++)
-                        acc[t][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s][t], bv[u], acc[t][u], 0, 0, 0);
-                }
-            }
-            if (kk + FS_PF < nk) {
-                const int pk = (kk + FS_PF) * 4 + l4;
-                const gptr_cd scol = Sig + (size_t)(pk < row_max ? pk : row_max) * ld;
-#pragma unroll
-                for (int t = 0; t < NT; t++) if (kk + FS_PF < kdiag[t] + 4) a[s][t] = scol[roff[t]];
-            }
-            if (kin == FS_PC / 4 - 1) {
-                if (c + 1 < n_chunk) {
-                    const lptr_d nxt = lt + ((c + 1) & 1) * (FS_PC * FS_LD);
-#pragma unroll
-                    for (int r = 0; r < FS_SR; r++) {
-                        const int p = wave + r * NW;
-                        if (p < FS_PC) nxt[p * FS_LD + lane] = st[r];
-                    }
-                }
-                __syncthreads();
-            }
+            for (int u = 0; u < 4; u++) acc[1][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[u], acc[1][u], 0, 0, 0);
         }
     }
+#pragma unroll
+    for (int r = 0; r < FS_RPW; r++) {
+        const int row = wave + r * FS_NWAVES, pp = (h + 1) * 16 + row;
+        if (row < 16) nxt[row * FS_LD + lane] = pp < M ? sv_nx1[r] : 0.0;
+    }
+    // rotate the rings (register moves)
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        a_cur[s][0] = a_nx1[s][0]; a_cur[s][1] = a_nx1[s][1];
+        a_nx1[s][0] = a_nx2[s][0]; a_nx1[s][1] = a_nx2[s][1];
+    }
+#pragma unroll
+    for (int r = 0; r < FS_RPW; r++) sv_nx1[r] = sv_nx2[r];
 }
 #endif
 
@@ -234,44 +224,50 @@ DEVNI void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W,
         for (int u = 0; u < 4; u++) { q_acc[u] = 0; m_acc[u] = 0; }
         for (int pass = 0; pass < n_pass; pass++) {
             const int jbase = pass * tiles_per_pass;
-            int jts[FS_JTW], roff[FS_JTW], kdiag[FS_JTW];
+            int jts[FS_JTW], roff[FS_JTW];
             jts[0] = jbase + B.wave;                          // w and 2 NW - 1 - w: with the triangular
             jts[1] = jbase + 2 * NW - 1 - B.wave;             // schedule both halves cost the same
-            int nt = 0;
 #pragma unroll
             for (int t = 0; t < FS_JTW; t++) {
-                if (jts[t] < nJ) nt = t + 1;
                 const int row = jts[t] * 16 + l15;
                 roff[t] = row < row_max ? row : row_max;
-                kdiag[t] = __builtin_amdgcn_readfirstlane(jts[t] < nJ ? jts[t] * 4 : -8);
             }
-            nt = __builtin_amdgcn_readfirstlane(nt);
+            // wave-uniform schedule: tile 0 is active for k-blocks 0..J0, tile 1 for 0..J1 (J0 < J1)
+            const int J0 = __builtin_amdgcn_readfirstlane(jts[0] < nJ ? jts[0] : -1);
+            const int J1 = __builtin_amdgcn_readfirstlane(jts[1] < nJ ? jts[1] : -1);
             const int last_tile = (jbase + tiles_per_pass < nJ ? jbase + tiles_per_pass : nJ) - 1;
-            const int n_chunk = (last_tile * 16 + 16 + FS_PC - 1) / FS_PC;    // k-blocks this pass needs
             d4 acc[FS_JTW][4];
 #pragma unroll
             for (int t = 0; t < FS_JTW; t++)
 #pragma unroll
                 for (int u = 0; u < 4; u++) acc[t][u] = d4{0, 0, 0, 0};
-            __syncthreads();
-            for (int p = B.wave; p < FS_PC; p += NW)
-                lt[p * FS_LD + B.lane] = (p < M) ? G[(size_t)lused[p] * K + istage] : 0.0;
-            __syncthreads();
-            switch (nt) {
-            case 2: fs_pass<2>(Sig, G, lused, lt, ld, row_max, roff, M, K, n_chunk, istage, B.wave, B.lane, NW, kdiag, acc); break;
-            case 1: fs_pass<1>(Sig, G, lused, lt, ld, row_max, roff, M, K, n_chunk, istage, B.wave, B.lane, NW, kdiag, acc); break;
-            default:                                          // no row tile: still keep the barriers
-                for (int c = 0; c < n_chunk; c++) {
-                    if (c + 1 < n_chunk) {
-                        const lptr_d nxt = lt + ((c + 1) & 1) * (FS_PC * FS_LD);
-                        for (int p = B.wave; p < FS_PC; p += NW) {
-                            const int pp = (c + 1) * FS_PC + p;
-                            nxt[p * FS_LD + B.lane] = (pp < M) ? G[(size_t)lused[pp] * K + istage] : 0.0;
-                        }
-                    }
-                    __syncthreads();
+            double a_cur[4][2], a_nx1[4][2], a_nx2[4][2], sv_nx1[FS_RPW], sv_nx2[FS_RPW];
+            {   // Sigma operands of k-blocks 0 and 1, Gram rows of k-block 1
+#pragma unroll
+                for (int sidx = 0; sidx < 4; sidx++) {
+                    const int pk0 = sidx * 4 + l4, pk1 = 16 + sidx * 4 + l4;
+                    const unsigned b0 = (unsigned)((pk0 < row_max ? pk0 : row_max) * ld);
+                    const unsigned b1 = (unsigned)((pk1 < row_max ? pk1 : row_max) * ld);
+                    a_cur[sidx][0] = Sig[b0 + roff[0]]; a_cur[sidx][1] = Sig[b0 + roff[1]];
+                    a_nx1[sidx][0] = Sig[b1 + roff[0]]; a_nx1[sidx][1] = Sig[b1 + roff[1]];
                 }
-                break;
+#pragma unroll
+                for (int r = 0; r < FS_RPW; r++) {
+                    const int pp = 16 + B.wave + r * FS_NWAVES;
+                    sv_nx1[r] = G[(size_t)lused[pp < M ? pp : M - 1] * K + istage];
+                }
+            }
+            __syncthreads();
+            for (int row = B.wave; row < 16; row += NW) lt[row * FS_LD + B.lane] = (row < M) ? G[(size_t)lused[row] * K + istage] : 0.0;
+            __syncthreads();
+            for (int h = 0; h <= last_tile; h++) {
+                const lptr_d cur = lt + (h & 1) * (FS_PC * FS_LD);
+                const lptr_d nxt = lt + ((h + 1) & 1) * (FS_PC * FS_LD);
+                const double w0 = (h < J0) ? 2.0 : 1.0, w1 = (h < J1) ? 2.0 : 1.0;
+                if (h <= J0) fs_kblock<3>(Sig, G, lused, cur, nxt, ld, row_max, roff[0], roff[1], h, w0, w1, M, K, istage, B.wave, B.lane, a_cur, a_nx1, a_nx2, sv_nx1, sv_nx2, acc);
+                else if (h <= J1) fs_kblock<2>(Sig, G, lused, cur, nxt, ld, row_max, roff[0], roff[1], h, w0, w1, M, K, istage, B.wave, B.lane, a_cur, a_nx1, a_nx2, sv_nx1, sv_nx2, acc);
+                else fs_kblock<0>(Sig, G, lused, cur, nxt, ld, row_max, roff[0], roff[1], h, w0, w1, M, K, istage, B.wave, B.lane, a_cur, a_nx1, a_nx2, sv_nx1, sv_nx2, acc);
+                __syncthreads();
             }
 #pragma unroll
             for (int t = 0; t < FS_JTW; t++) {
@@ -464,7 +460,7 @@ DEVNI void gm_sq_update(const Blk &B, const FoldDev &F, const GmWork &W, int K, 
 #else
     // K x M mat-vec over Gram rows: `used`/`vec` staged in LDS, SQ_Q features per thread so that
     // SQ_Q independent coalesced row loads are in flight per active feature.
-    constexpr int SQ_Q = 5;
+    constexpr int SQ_Q = 10;
     const gptr_cd G = as_global(F.G);
     const lptr_d lvec = as_lds(B.pool);
     const lptr_i lused = as_lds((int *)(B.pool + ((M + 1) & ~1)));

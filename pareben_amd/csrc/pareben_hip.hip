@@ -19,6 +19,11 @@
 #include <numeric>
 #include <string>
 
+#ifndef FIT_THREADS
+#define FIT_THREADS 512          // 8 wavefronts per fit workgroup: 256 VGPRs per lane for the matrix-core pass
+#endif
+#define FS_NWAVES (FIT_THREADS / 64)
+
 #include "../../include/pareben_hip.h"
 #include "types.h"
 #include "blk.h"
@@ -268,9 +273,6 @@ __device__ inline BmWork bm_carve(char *base, int K, const BmLayout &L)
 // ------------------------------------------------------------------------------------------
 // fit kernels
 
-#ifndef FIT_THREADS
-#define FIT_THREADS 1024
-#endif
 
 struct CvParams {
     const FoldDev *folds;
