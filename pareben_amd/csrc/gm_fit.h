@@ -108,62 +108,60 @@ template <class T> DEV T *uni_ptr(T *p)
 
 // One 16-row k-block (4 k-steps) for the row tiles in MASK (bit 0: tile 0, bit 1: tile 1) against the
 // four 16-feature sub-tiles of the staged Gram block.  Everything that comes from beyond L2 is
-// fetched TWO k-blocks ahead into registers: the Sigma operands of block h+2 (ring a_cur -> a_nx1 ->
-// a_nx2) and the Gram rows of block h+2 (sv_nx1 -> sv_nx2; block h+1's rows are written to LDS at the
-// end of this block).  Straight-line on purpose: no branch separates a load from its use, so the
-// compiler keeps counted s_waitcnt vmcnt(N) and the prefetches overlap two blocks of MFMAs.
+// fetched TWO k-blocks ahead into three-slot register rings indexed at compile time (CUR = h mod 3):
+// block h consumes slot CUR, issues the loads of block h+2 into slot CUR+2 and writes the Gram rows
+// of block h+1 (slot CUR+1, loaded during block h-1) to LDS.  No register copies and no branch
+// between a load and its use: the compiler keeps counted s_waitcnt vmcnt(N) and the loads stay in
+// flight across two blocks of MFMAs and two barriers.
 //   w0 / w1: 2.0 while THIS k-block is strictly below the tile's diagonal block, 1.0 on it
 //   (Sigma is symmetric: row tile J only visits k-blocks P <= J and counts P < J twice; doubling an
 //   operand is exact).
 #define FS_RPW ((16 + FS_NWAVES - 1) / FS_NWAVES)
-template <int MASK>
+// The tile activity (act0 / act1, wave-uniform) only guards MFMA groups -- never a load -- so the
+// load/wait bookkeeping is identical on every path; an inactive tile's operand loads are pointed at
+// one fixed, cache-resident address.
+template <int CUR>
 DEV void fs_kblock(gptr_cd Sig, gptr_cd G, lptr_i lused, lptr_d cur, lptr_d nxt, int ld, int row_max,
-                   int roff0, int roff1, int h, double w0, double w1, int M, int K, int istage,
-                   int wave, int lane, double (&a_cur)[4][2], double (&a_nx1)[4][2], double (&a_nx2)[4][2],
-                   double (&sv_nx1)[FS_RPW], double (&sv_nx2)[FS_RPW], d4 (&acc)[2][4])
+                   int roff0, int roff1, int h, bool act0, bool act1, bool nxt0, bool nxt1, double w0, double w1,
+                   int M, int K, int istage, int wave, int lane, double (&a)[3][4][2], double (&sv)[3][FS_RPW],
+                   d4 (&acc)[2][4])
 {
+    constexpr int NX1 = (CUR + 1) % 3, NX2 = (CUR + 2) % 3;
     const int l15 = lane & 15, l4 = lane >> 4;
 #pragma unroll
     for (int r = 0; r < FS_RPW; r++) {
         const int pp = (h + 2) * 16 + wave + r * FS_NWAVES;
-        sv_nx2[r] = G[(size_t)lused[pp < M ? pp : M - 1] * K + istage];
+        sv[NX2][r] = G[(size_t)lused[pp < M ? pp : M - 1] * K + istage];
     }
     const lptr_d brow = cur + l4 * FS_LD + l15;
+    const int r0 = nxt0 ? roff0 : 0, r1 = nxt1 ? roff1 : 0;    // tile retired two blocks from now: fixed address
 #pragma unroll
     for (int s = 0; s < 4; s++) {
         double bv[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) bv[u] = brow[s * 4 * FS_LD + u * 16];
-        if (MASK) {
+        {
             const int pk = (h + 2) * 16 + s * 4 + l4;
-            const unsigned base = (unsigned)((pk < row_max ? pk : row_max) * ld);
-            if (MASK & 1) a_nx2[s][0] = Sig[base + roff0];
-            if (MASK & 2) a_nx2[s][1] = Sig[base + roff1];
+            const int pc = pk < row_max ? pk : row_max;
+            a[NX2][s][0] = Sig[(unsigned)((nxt0 ? pc : 0) * ld + r0)];
+            a[NX2][s][1] = Sig[(unsigned)((nxt1 ? pc : 0) * ld + r1)];
         }
-        if (MASK & 1) {
-            const double av = a_cur[s][0] * w0;                // doubled at use, not at load
+        const double av0 = a[CUR][s][0] * w0;                  // doubled at use, not at load
+        const double av1 = a[CUR][s][1] * w1;
+        if (act0) {
 #pragma unroll
-            for (int u = 0; u < 4; u++) acc[0][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[u], acc[0][u], 0, 0, 0);
+            for (int u = 0; u < 4; u++) acc[0][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av0, bv[u], acc[0][u], 0, 0, 0);
         }
-        if (MASK & 2) {
-            const double av = a_cur[s][1] * w1;
+        if (act1) {
 #pragma unroll
-            for (int u = 0; u < 4; u++) acc[1][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[u], acc[1][u], 0, 0, 0);
+            for (int u = 0; u < 4; u++) acc[1][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av1, bv[u], acc[1][u], 0, 0, 0);
         }
     }
 #pragma unroll
     for (int r = 0; r < FS_RPW; r++) {
         const int row = wave + r * FS_NWAVES, pp = (h + 1) * 16 + row;
-        if (row < 16) nxt[row * FS_LD + lane] = pp < M ? sv_nx1[r] : 0.0;
+        if (row < 16) nxt[row * FS_LD + lane] = pp < M ? sv[NX1][r] : 0.0;
     }
-    // rotate the rings (register moves)
-#pragma unroll
-    for (int s = 0; s < 4; s++) {
-        a_cur[s][0] = a_nx1[s][0]; a_cur[s][1] = a_nx1[s][1];
-        a_nx1[s][0] = a_nx2[s][0]; a_nx1[s][1] = a_nx2[s][1];
-    }
-#pragma unroll
-    for (int r = 0; r < FS_RPW; r++) sv_nx1[r] = sv_nx2[r];
 }
 #endif
 
@@ -241,34 +239,41 @@ DEVNI void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W,
             for (int t = 0; t < FS_JTW; t++)
 #pragma unroll
                 for (int u = 0; u < 4; u++) acc[t][u] = d4{0, 0, 0, 0};
-            double a_cur[4][2], a_nx1[4][2], a_nx2[4][2], sv_nx1[FS_RPW], sv_nx2[FS_RPW];
-            {   // Sigma operands of k-blocks 0 and 1, Gram rows of k-block 1
+            double a[3][4][2], sv[3][FS_RPW];
+            {   // Sigma operands of k-blocks 0 and 1 (slots 0, 1), Gram rows of k-block 1 (slot 1)
 #pragma unroll
                 for (int sidx = 0; sidx < 4; sidx++) {
                     const int pk0 = sidx * 4 + l4, pk1 = 16 + sidx * 4 + l4;
                     const unsigned b0 = (unsigned)((pk0 < row_max ? pk0 : row_max) * ld);
                     const unsigned b1 = (unsigned)((pk1 < row_max ? pk1 : row_max) * ld);
-                    a_cur[sidx][0] = Sig[b0 + roff[0]]; a_cur[sidx][1] = Sig[b0 + roff[1]];
-                    a_nx1[sidx][0] = Sig[b1 + roff[0]]; a_nx1[sidx][1] = Sig[b1 + roff[1]];
+                    a[0][sidx][0] = Sig[b0 + roff[0]]; a[0][sidx][1] = Sig[b0 + roff[1]];
+                    a[1][sidx][0] = Sig[b1 + roff[0]]; a[1][sidx][1] = Sig[b1 + roff[1]];
                 }
 #pragma unroll
                 for (int r = 0; r < FS_RPW; r++) {
                     const int pp = 16 + B.wave + r * FS_NWAVES;
-                    sv_nx1[r] = G[(size_t)lused[pp < M ? pp : M - 1] * K + istage];
+                    sv[1][r] = G[(size_t)lused[pp < M ? pp : M - 1] * K + istage];
                 }
             }
             __syncthreads();
             for (int row = B.wave; row < 16; row += NW) lt[row * FS_LD + B.lane] = (row < M) ? G[(size_t)lused[row] * K + istage] : 0.0;
             __syncthreads();
-            for (int h = 0; h <= last_tile; h++) {
-                const lptr_d cur = lt + (h & 1) * (FS_PC * FS_LD);
-                const lptr_d nxt = lt + ((h + 1) & 1) * (FS_PC * FS_LD);
-                const double w0 = (h < J0) ? 2.0 : 1.0, w1 = (h < J1) ? 2.0 : 1.0;
-                if (h <= J0) fs_kblock<3>(Sig, G, lused, cur, nxt, ld, row_max, roff[0], roff[1], h, w0, w1, M, K, istage, B.wave, B.lane, a_cur, a_nx1, a_nx2, sv_nx1, sv_nx2, acc);
-                else if (h <= J1) fs_kblock<2>(Sig, G, lused, cur, nxt, ld, row_max, roff[0], roff[1], h, w0, w1, M, K, istage, B.wave, B.lane, a_cur, a_nx1, a_nx2, sv_nx1, sv_nx2, acc);
-                else fs_kblock<0>(Sig, G, lused, cur, nxt, ld, row_max, roff[0], roff[1], h, w0, w1, M, K, istage, B.wave, B.lane, a_cur, a_nx1, a_nx2, sv_nx1, sv_nx2, acc);
-                __syncthreads();
+#define FS_STEP(CURSLOT, hh)                                                                                         \
+            if ((hh) <= last_tile) {                                                                                 \
+                const int h_ = (hh);                                                                                 \
+                const lptr_d cur = lt + (h_ & 1) * (FS_PC * FS_LD);                                                  \
+                const lptr_d nxt = lt + ((h_ + 1) & 1) * (FS_PC * FS_LD);                                            \
+                const double w0 = (h_ < J0) ? 2.0 : 1.0, w1 = (h_ < J1) ? 2.0 : 1.0;                                 \
+                fs_kblock<CURSLOT>(Sig, G, lused, cur, nxt, ld, row_max, roff[0], roff[1], h_, h_ <= J0, h_ <= J1,   \
+                                   h_ + 2 <= J0, h_ + 2 <= J1, w0, w1, M, K, istage, B.wave, B.lane, a, sv, acc);   \
+                __syncthreads();                                                                                     \
             }
+            for (int h = 0; h <= last_tile; h += 3) {
+                FS_STEP(0, h)
+                FS_STEP(1, h + 1)
+                FS_STEP(2, h + 2)
+            }
+#undef FS_STEP
 #pragma unroll
             for (int t = 0; t < FS_JTW; t++) {
                 if (jts[t] < nJ) {
