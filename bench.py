@@ -117,6 +117,20 @@ def main():
 
     total_fits = n_cells * nF
     result = None
+    # HBM traffic of the dominant kernel comes from a separate rocprofv3 PMC run of this same command
+    # (profiles/<round>/traffic.json); it is attached only when the workload is the one profiled.
+    traffic, traffic_note = None, None
+    try:
+        import glob
+        for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")))[::-1]:
+            tj = json.load(open(tf))
+            if tj.get("workload", "").startswith("synthetic gaussian n=%d p=%d nFolds=%d grid=%dalpha x %dlambda" %
+                                                 (args.n, args.p, args.nfolds, args.nalpha, args.nlambda)) and world == 1:
+                traffic = tj["corrected_bytes"] / tj.get("launches", 1)
+                traffic_note = "PMC (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch from %s; raw %.3g B" % (os.path.relpath(tf, ROOT), tj["raw_bytes"])
+                break
+    except Exception:
+        pass
     if rank == 0:
         bytes_, flops = algorithmic_bytes_flops(state["cnt"], args.p)
         fit_ms = state["timing"]["fit_ms"]
@@ -142,7 +156,7 @@ def main():
                        "aborted_fits": int(np.sum(state["status"] & 8 != 0)),
                        "launch": state["launch"], "kernel_ms": state["timing"]},
             "roofline": {"bound": "hbm", "kernel": "gm_cv_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "algorithmic_bytes_per_launch": bytes_, "launch_ms": fit_ms,
                          "fp64_vector": {"achieved_tflops": flops / (fit_ms * 1e-3) / 1e12, "peak_tflops": FP64_PEAK_TFLOPS,
                                          "frac": flops / (fit_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}},
