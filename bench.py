@@ -63,11 +63,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
+    # PAREBEN_BENCH_BACKEND=gloo + PAREBEN_BENCH_ONE_DEVICE=1 rehearse the N > 1 path on a one-GPU box
+    backend = os.environ.get("PAREBEN_BENCH_BACKEND", "nccl")
+    dev_index = 0 if os.environ.get("PAREBEN_BENCH_ONE_DEVICE") else local_rank
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         dist = None
         torch.cuda.set_device(0)
@@ -83,7 +89,7 @@ def main():
     n_cells, nF = len(alpha), args.nfolds
     mine = shard_cells(alpha, lam, rank, world)
 
-    ctx = pareben_amd.Context(X, y, folds, nF, device=local_rank if world > 1 else 0)   # H2D staging, untimed
+    ctx = pareben_amd.Context(X, y, folds, nF, device=dev_index if world > 1 else 0)   # H2D staging, untimed
     state = {}
 
     def step():
@@ -111,7 +117,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
