@@ -39,7 +39,7 @@ extern "C" {
 #define PAREBEN_ST_OVERFLOW 1     /* active set reached the workspace capacity       */
 #define PAREBEN_ST_CHOLESKY 2     /* Hessian not positive definite                   */
 #define PAREBEN_ST_STALE    4     /* reference's stale-slot delete path was taken    */
-#define PAREBEN_ST_ABORT    8     /* fit stopped early; its score is not meaningful  */
+#define PAREBEN_ST_ABORT    8     /* fit stopped early; its fold_err entry is NaN     */
 
 /* number of int64 counters per fit in counters[] (order: n_outer, n_inner, n_add, n_del,
  * n_reest, n_fullstat, sum_m_action, sum_m_full, sum_m2_full, m_final, m_max, status) */
@@ -74,6 +74,11 @@ int pareben_ctx_create(pareben_ctx **out, int device,
  * Inputs are already resident; the call launches the per-fold preparation kernels (row split,
  * column statistics, Gram matrices) and the fit kernel on the context's stream, then copies the
  * small result arrays back.
+ * Gaussian prior, large p: when n_folds p x p Gram matrices do not fit in HBM beside the fit
+ * workspaces, the context keeps a pool of Gram rows per fold instead and the fit kernel fills it on
+ * first use (plus a few private rows per workgroup once a pool is full): same results to rounding,
+ * one sweep of the fold's design per new row.  The environment variable PAREBEN_GRAM_ROWS=<rows
+ * per fold>, read by pareben_ctx_create, forces that mode (diagnostics).
  */
 int pareben_ctx_run(pareben_ctx *ctx, int n_cells, const double *alpha, const double *lambda,
                     double *fold_err, int32_t *status, int64_t *counters);

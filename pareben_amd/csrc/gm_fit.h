@@ -178,8 +178,8 @@ DEVNI void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W,
         double quad = 0, bm = 0;
         for (int j = 0; j < M; j++) {
             double a = 0;
-            for (int p = 0; p < M; p++) a += F.G[(size_t)W.used[p] * K + i] * W.Sig[(size_t)j * ld + p];
-            double bj = F.G[(size_t)W.used[j] * K + i];
+            for (int p = 0; p < M; p++) a += F.G[(size_t)W.rowid[p] * K + i] * W.Sig[(size_t)j * ld + p];
+            double bj = F.G[(size_t)W.rowid[j] * K + i];
             quad += a * bj;
             bm += bj * W.mu[j];
         }
@@ -207,7 +207,7 @@ DEVNI void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W,
     K = uni(K); M = uni(M);
     const int ld = uni(W.ld);
     __syncthreads();
-    for (int p = B.tid; p < M; p += B.nthr) lused[p] = W.used[p];
+    for (int p = B.tid; p < M; p += B.nthr) lused[p] = W.rowid[p];
     __syncthreads();
     const int NW = uni(B.nwave);
     const int l15 = B.lane & 15, l4 = B.lane >> 4;
@@ -329,7 +329,7 @@ DEV void gm_fullstat(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmS
     const double beta = S.beta;
     if (very_first) {
         if (B.tid == 0) {
-            W.H[0] = F.G[0] * beta + W.A[0];
+            W.H[0] = F.G[(size_t)W.rowid[0] * K] * beta + W.A[0];
             W.Sig[0] = 1 / W.H[0];
         }
     }
@@ -461,7 +461,7 @@ DEVNI void gm_sq_update(const Blk &B, const FoldDev &F, const GmWork &W, int K, 
 #ifdef PAREBEN_HOST_EMUL
     PAR(i, K) {
         double a = 0;
-        for (int j = 0; j < M; j++) a += F.G[(size_t)W.used[j] * K + i] * vec[j];
+        for (int j = 0; j < M; j++) a += F.G[(size_t)W.rowid[j] * K + i] * vec[j];
 #else
     // K x M mat-vec over Gram rows: `used`/`vec` staged in LDS, SQ_Q features per thread so that
     // SQ_Q independent coalesced row loads are in flight per active feature.
@@ -470,7 +470,7 @@ DEVNI void gm_sq_update(const Blk &B, const FoldDev &F, const GmWork &W, int K, 
     const lptr_d lvec = as_lds(B.pool);
     const lptr_i lused = as_lds((int *)(B.pool + ((M + 1) & ~1)));
     blk_sync(B);
-    PAR(j, M) { lvec[j] = vec[j]; lused[j] = W.used[j]; }
+    PAR(j, M) { lvec[j] = vec[j]; lused[j] = W.rowid[j]; }
     blk_sync(B);
     for (int ib = 0; ib < K; ib += SQ_Q * B.nthr) {
         double accq[SQ_Q];
@@ -534,12 +534,110 @@ DEVNI void gm_reestimate(const Blk &B, const FoldDev &F, const GmWork &W, int K,
     gm_sq_update(B, F, W, K, M, W.v2, 0, S.beta, kappa, mujj, nullptr);
 }
 
+// Gram row of feature u = the reference's BASIS_PHI row for that basis (MainEff.c:1608-1630):
+// G[i] = x_i . (x_u / scale_u) / scale_i.  Returns the row id r with the row at F.G + r*K, or -1.
+//   full mode (F.lazy == 0): every row was computed by gram_kernel; r = u.
+//   lazy mode: K x K does not fit in HBM.  Rows live in a per-fold pool shared by every workgroup
+//   working on that fold and are computed on first use by sweeping the fold's design once (what
+//   the reference does at every add of every fit).  slot_of[u]: -1 absent, -2 being computed,
+//   >= 0 pool slot, published with an agent-scope release / consumed behind an agent-scope acquire.
+//   A row is written once before it is published and never again, and its values do not depend on
+//   who computed it (fixed summation order), so results stay independent of timing.  A waiting
+//   workgroup waits only for one that is computing (the grid is fully resident and a computing
+//   workgroup never waits); the wait is bounded anyway and falls back to a private copy.
+//   When the pool is exhausted the row goes into one of the workgroup's private rows (released
+//   again at delete / end of fit): the reference's own per-fit BASIS_PHI, one design sweep per add.
+#ifdef PAREBEN_HOST_EMUL
+DEV double wave_sum(double v) { return v; }
+#define ROW_LOAD(p) (*(p))
+#define ROW_CAS(p, e, d) (*(p) == (e) ? (*(p) = (d), true) : ((e) = *(p), false))
+#define ROW_STORE(p, v) (*(p) = (v))
+#define ROW_FETCH_ADD(p, v) ((*(p) += (v)) - (v))
+#else
+#define ROW_LOAD(p) __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define ROW_CAS(p, e, d) __hip_atomic_compare_exchange_strong(p, &(e), d, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define ROW_STORE(p, v) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define ROW_FETCH_ADD(p, v) __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#endif
+#define ROW_SPIN_MAX 400000       // x ~1 us: far beyond one row sweep
+DEVNI int gm_row(const Blk &B, const FoldDev &F, const GmWork &W, int K, int u)
+{
+    if (!F.lazy) return u;
+    enum { R_OWNER = -3, R_PRIVATE = -4 };
+    blk_sync(B);
+    if (B.tid == 0) {
+        int *st = F.slot_of + u;
+        int s = ROW_LOAD(st);
+        if (s == -1) {
+            int expect = -1;
+            if (ROW_CAS(st, expect, -2)) s = R_OWNER; else s = expect;
+        }
+#ifndef PAREBEN_HOST_EMUL
+        for (int spin = 0; s == -2 && spin < ROW_SPIN_MAX; spin++) {
+            __builtin_amdgcn_s_sleep(32);
+            s = ROW_LOAD(st);
+        }
+#endif
+        if (s == -2 || s == -1) s = R_PRIVATE;                  // timed out / the owner found the pool full
+        int my = -1;
+        if (s == R_OWNER) {
+            if (ROW_LOAD(F.pool_next) < F.pool_rows) my = ROW_FETCH_ADD(F.pool_next, 1);
+            if (my >= 0 && my < F.pool_rows) my += F.pool_base;
+            else { my = -1; ROW_STORE(st, -1); s = R_PRIVATE; }    // pool exhausted
+        }
+        if (s == R_PRIVATE && W.pfree[0] > 0) my = W.pfree[W.pfree[0]--];   // one of this fit's own rows
+        B.ired[0] = s;
+        B.ired[1] = my;
+#ifndef PAREBEN_HOST_EMUL
+        if (s >= 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+#endif
+    }
+    blk_sync(B);
+    const int s = B.ired[0], my = B.ired[1];
+    blk_sync(B);
+    if (s >= 0) return s;
+    if (my < 0) return -1;
+    const int N = F.N;
+    double *row = const_cast<double *>(F.G) + (size_t)my * K;
+    const double *xu = F.X + (size_t)u * N;
+    const double ru = F.rscale[u];
+    const bool in_lds = N <= B.pool_n;
+    if (in_lds) {
+        PAR(h, N) B.pool[h] = xu[h] * ru;
+        blk_sync(B);
+    }
+    for (int i = B.wave; i < K; i += B.nwave) {
+        const double *xi = F.X + (size_t)i * N;
+        double a = 0;
+        if (in_lds) for (int h = B.lane; h < N; h += BLK_LANES) a += xi[h] * B.pool[h];
+        else for (int h = B.lane; h < N; h += BLK_LANES) a += xi[h] * (xu[h] * ru);
+        a = wave_sum(a);
+        if (B.lane == 0) row[i] = a / F.scale[i];
+    }
+#ifndef PAREBEN_HOST_EMUL
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its stores
+#endif
+    blk_sync(B);
+    if (s == R_OWNER && B.tid == 0) {
+#ifndef PAREBEN_HOST_EMUL
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        ROW_STORE(F.slot_of + u, my);
+    }
+    blk_sync(B);
+    return my;
+}
+
 // add feature nu, MainEff.c:1585-1723 + :613-627
-DEVNI void gm_add(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScalars &S, int nu, double newA)
+DEVNI void gm_add(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScalars &S, int nu, int rid, double newA)
 {
     const int M = S.M, ld = W.ld;
     const double beta = S.beta;
-    const double *row = F.G + (size_t)nu * K;                 // x_i . phi_nu / scale_i
+    const double *row = F.G + (size_t)rid * K;                // x_i . phi_nu / scale_i (Gram row of nu)
     PAR(l, M) W.v1[l] = beta * row[W.used[l]];                // beta Phi' phi
     blk_sync(B);
     PAR(i, M) {
@@ -565,6 +663,7 @@ DEVNI void gm_add(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScal
         W.A[M] = newA;
         W.mu[M] = mui;
         W.used[M] = nu;
+        W.rowid[M] = rid;
         W.upos[nu] = M;
     }
     gm_sq_update(B, F, W, K, M, W.v2, 1, beta, sii, mui, row);
@@ -582,6 +681,7 @@ DEVNI void gm_delete(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmS
     const double sjj = W.v2[jj];
     const int mujj = (int)W.mu[jj];                           // Q2: int truncation
     const int gone = W.used[jj];
+    const int gone_row = W.rowid[jj];
     gm_sq_update(B, F, W, K, M, W.v2, 2, S.beta, sjj, (double)mujj, nullptr);
     PAR(i, M) W.mu[i] = W.mu[i] - mujj * W.v2[i] / sjj;
     for (int j = B.wave; j < M; j += B.nwave) {
@@ -603,12 +703,14 @@ DEVNI void gm_delete(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmS
             W.A[jj] = W.A[last];
             W.mu[jj] = W.mu[last];
             W.used[jj] = W.used[last];
+            W.rowid[jj] = W.rowid[last];
             W.upos[W.used[last]] = jj;
         }
     }
     if (B.tid == 0) {
         if (gone == nu) W.upos[gone] = UP_FREE;
         else { W.upos[gone] = UP_LOST; }
+        if (F.lazy && gone_row >= W.priv_base && gone_row < W.priv_base + W.priv_rows) W.pfree[++W.pfree[0]] = gone_row;
     }
     S.M = last;
     blk_sync(B);
@@ -780,7 +882,7 @@ DEVNI int gm_final_update(const Blk &B, const FoldDev &F, const GmWork &W, int K
         for (int i = B.lane; i < M; i += BLK_LANES) {
             const int ui = W.used[i];
             // Phi_i.Phi_j from the Gram matrix; one triangle so that H is exactly symmetric
-            double h = (i <= j ? F.G[(size_t)ui * K + uj] : F.G[(size_t)uj * K + ui]) * beta;
+            double h = (i <= j ? F.G[(size_t)W.rowid[i] * K + uj] : F.G[(size_t)W.rowid[j] * K + ui]) * beta;
             if (i == j) h += W.A[i];
             W.H[(size_t)j * ld + i] = h;
             W.Sig[(size_t)j * ld + i] = h;
@@ -815,11 +917,18 @@ DEV int gm_inner(const Blk &B, const FoldDev &F, const GmWork &W, int K, double 
             S.beta = 1 / ((sd * 0.1) * (sd * 0.1));
         }
         PAR(i, K) W.upos[i] = UP_FREE;
+        if (B.tid == 0 && F.lazy) {                              // all private rows are free again
+            W.pfree[0] = W.priv_rows;
+            for (int j = 0; j < W.priv_rows; j++) W.pfree[1 + j] = W.priv_base + W.priv_rows - 1 - j;
+        }
+        const int rid0 = gm_row(B, F, W, K, 0);
+        if (rid0 < 0) { S.status |= ST_OVERFLOW | ST_ABORT; return 1; }
         blk_sync(B);
         if (B.tid == 0) {
             W.used[0] = 0;
+            W.rowid[0] = rid0;
             W.upos[0] = 0;
-            const double p = F.G[0] * S.beta;
+            const double p = F.G[(size_t)rid0 * K] * S.beta;
             const double q = (F.bt0[0] - S.b * F.cs[0]) * S.beta;
             double a0 = p * p / (q * q - p);
             if (a0 < 0) a0 = S.v.alpha_max;
@@ -892,8 +1001,10 @@ DEV int gm_inner(const Blk &B, const FoldDev &F, const GmWork &W, int K, double 
                     upd = true;
                 } else if (sel == ACT_ADD) {
                     if (S.M + 1 > W.cap) { S.status |= ST_OVERFLOW | ST_ABORT; return 1; }
+                    const int rid = gm_row(B, F, W, K, nu);
+                    if (rid < 0) { S.status |= ST_OVERFLOW | ST_ABORT; return 1; }
                     CNT(c.n_add++; c.sum_m_action += S.M);
-                    gm_add(B, F, W, K, S, nu, newA);
+                    gm_add(B, F, W, K, S, nu, rid, newA);
                     upd = true;
                 } else if (sel == ACT_DEL) {
                     CNT(c.n_del++; c.sum_m_action += S.M);

@@ -204,7 +204,7 @@ static WsLayout ws_layout(int K, int cap)
     size_t o = 0;
     L.offK = o;   o += align_up((size_t)K * (7 * sizeof(double) + 2 * sizeof(int) + 1), 256);
     L.offSig = o; o += align_up((size_t)2 * cap * cap * sizeof(double), 256);
-    L.offM = o;   o += align_up((size_t)(cap + 1) * (7 * sizeof(double) + sizeof(int)), 256);
+    L.offM = o;   o += align_up((size_t)(cap + 2) * (7 * sizeof(double) + 3 * sizeof(int)), 256);
     L.bytes = align_up(o, 4096);
     return L;
 }
@@ -225,6 +225,9 @@ __device__ inline GmWork ws_carve(char *base, int K, int cap, size_t offK, size_
     W.A = d; d += c1; W.mu = d; d += c1; W.gam = d; d += c1;
     W.v1 = d; d += c1; W.v2 = d; d += c1; W.v3 = d; d += c1; W.v4 = d; d += c1;
     W.used = (int *)d;
+    W.rowid = W.used + c1;
+    W.pfree = W.rowid + c1;
+    W.priv_base = 0; W.priv_rows = 0;
     W.e = nullptr;
     W.cap = cap; W.ld = cap;
     return W;
@@ -286,6 +289,7 @@ struct CvParams {
     char *ws;
     size_t ws_stride, offK, offSig, offM;
     int K, cap, n_folds, n_units;
+    int priv_base0, priv_rows;         // lazy Gram mode: private rows of workgroup b start at priv_base0 + b * priv_rows
     GmVariant v;
 };
 
@@ -323,7 +327,9 @@ __global__ __launch_bounds__(FIT_THREADS) void gm_cv_kernel(CvParams P)
     __shared__ FitCounters s_cnt;
     __shared__ long long s_ph[8];
     const Blk B = make_blk();
-    const GmWork W = ws_carve(P.ws + (size_t)blockIdx.x * P.ws_stride, P.K, P.cap, P.offK, P.offSig, P.offM);
+    GmWork W = ws_carve(P.ws + (size_t)blockIdx.x * P.ws_stride, P.K, P.cap, P.offK, P.offSig, P.offM);
+    W.priv_rows = P.priv_rows;
+    W.priv_base = P.priv_base0 + (int)blockIdx.x * P.priv_rows;
     for (;;) {
         __syncthreads();
         if (threadIdx.x == 0) s_unit = atomicAdd(P.queue, 1);
@@ -351,7 +357,7 @@ __global__ __launch_bounds__(FIT_THREADS) void gm_cv_kernel(CvParams P)
         }
 #endif
         if (threadIdx.x == 0) {
-            P.fold_err[unit] = sse;
+            P.fold_err[unit] = (S.status & ST_ABORT) ? __builtin_nan("") : sse;   // an aborted fit has no score
             P.status[unit] = S.status;
             if (P.counters) store_counters(P.counters + (size_t)unit * PAREBEN_NCOUNTERS, s_cnt);
         }
@@ -393,7 +399,7 @@ __global__ __launch_bounds__(FIT_THREADS) void bm_cv_kernel(BmCvParams P)
         bm_fit(B, F, W, P.K, P.lambda[cell], P.alpha[cell], S, &ll);
         const double score = bm_fold_loglik(B, F, W, S);
         if (threadIdx.x == 0) {
-            P.fold_err[unit] = score;
+            P.fold_err[unit] = (S.status & ST_ABORT) ? __builtin_nan("") : score;
             P.status[unit] = S.status;
             if (P.counters) store_counters(P.counters + (size_t)unit * PAREBEN_NCOUNTERS, s_cnt);
         }
@@ -476,6 +482,10 @@ struct pareben_ctx {
     double last_ms[3] = {0, 0, 0};
     int64_t launch_info[4] = {0, 0, 0, 0};
     int n_cu = 0;
+    // on-demand Gram rows (K x K per fold does not fit): [lazy_hdr ints of pool counters][n_folds x K slots]
+    int lazy = 0, pool_rows = 0, priv_rows = 0, max_blocks = 0, lazy_hdr = 0;
+    int *d_lazy = nullptr;
+    double *d_rows = nullptr;   // lazy mode: n_folds pools of pool_rows rows, then max_blocks x priv_rows private rows
 };
 
 static int default_cap(int K, int max_active)
@@ -502,7 +512,7 @@ extern "C" int pareben_ctx_destroy(pareben_ctx *c)
         hipFree(f.d_tr); hipFree(f.d_te); hipFree(f.X); hipFree(f.y); hipFree(f.Xte); hipFree(f.yte);
         hipFree(f.scale); hipFree(f.rscale); hipFree(f.bt0); hipFree(f.cs); hipFree(f.G); hipFree(f.ystat);
     }
-    hipFree(c->d_basis); hipFree(c->d_y); hipFree(c->d_folds); hipFree(c->d_ws);
+    hipFree(c->d_basis); hipFree(c->d_y); hipFree(c->d_folds); hipFree(c->d_ws); hipFree(c->d_lazy); hipFree(c->d_rows);
     for (auto &e : c->ev) if (e) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -563,11 +573,50 @@ static int ctx_create_impl(pareben_ctx **out, int device, const double *basis, i
         CK(dmalloc(&H.Xte, (size_t)H.nte * KF)); CK(dmalloc(&H.yte, (size_t)H.nte));
         CK(dmalloc(&H.scale, KF)); CK(dmalloc(&H.rscale, KF));
         CK(dmalloc(&H.bt0, KF)); CK(dmalloc(&H.cs, KF));
-        if (prior == PAREBEN_PRIOR_GAUSSIAN) CK(dmalloc(&H.G, KF * KF));   // binomial: no Gram matrix (weights change)
         CK(dmalloc(&H.ystat, (size_t)2));
+    }
+    if (prior == PAREBEN_PRIOR_GAUSSIAN) {         // binomial: no Gram matrix (the weights change)
+        // Full per-fold Gram matrices when they fit beside the fit workspaces; else one buffer of
+        // Gram rows filled on demand by the fit kernel (gm_row): a shared pool per fold plus a few
+        // private rows per workgroup for when a pool runs out.  PAREBEN_GRAM_ROWS=<rows per fold>
+        // forces the second mode (diagnostics / tests).
+        size_t free_b = 0, total_b = 0;
+        CK(hipMemGetInfo(&free_b, &total_b));
+        int occ = 1;
+        CK(hipFuncSetAttribute((const void *)gm_cv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FIT_BYTES));
+        CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, gm_cv_kernel, FIT_THREADS, LDS_FIT_BYTES));
+        c->max_blocks = c->n_cu * std::max(occ, 1);
+        const size_t ws_guess = (size_t)c->max_blocks * ws_layout(c->kfull, c->cap).bytes + ((size_t)1 << 30);
+        const size_t avail = (free_b > ws_guess ? free_b - ws_guess : 0) / 10 * 9;
+        const size_t row_b = KF * sizeof(double);
+        const char *force = getenv("PAREBEN_GRAM_ROWS");
+        const long long forced = force ? atoll(force) : 0;
+        if (forced > 0 || (size_t)n_folds * KF * row_b > avail) {
+            c->lazy = 1;
+            long long priv = std::min<long long>(c->cap, (long long)(avail / 4 / ((size_t)c->max_blocks * row_b)));
+            long long rows = (long long)((avail - (size_t)priv * c->max_blocks * row_b) / ((size_t)n_folds * row_b));
+            if (forced > 0) { rows = forced; priv = c->cap; }
+            rows = std::min<long long>(rows, (long long)KF);
+            if ((rows + priv < 1) || (rows * n_folds + priv * c->max_blocks) > 2000000000LL) {
+                pareben_ctx_destroy(c);
+                return fail(PAREBEN_ENOMEM, "no room for Gram rows");
+            }
+            c->pool_rows = (int)rows; c->priv_rows = (int)priv;
+            CK(dmalloc(&c->d_rows, ((size_t)rows * n_folds + (size_t)priv * c->max_blocks) * KF));
+            c->lazy_hdr = (n_folds + 63) / 64 * 64;
+            CK(dmalloc(&c->d_lazy, (size_t)c->lazy_hdr + (size_t)n_folds * KF));
+        } else {
+            for (int f = 0; f < n_folds; f++) CK(dmalloc(&c->folds[f].G, KF * KF));
+        }
+    }
+    for (int f = 0; f < n_folds; f++) {
+        FoldHost &H = c->folds[f];
         FoldDev &D = fd[f];
         D.X = H.X; D.y = H.y; D.Xte = H.Xte; D.yte = H.yte; D.scale = H.scale; D.rscale = H.rscale;
-        D.bt0 = H.bt0; D.cs = H.cs; D.G = H.G; D.ymean = 0; D.varY = 0; D.N = H.N; D.nte = H.nte;
+        D.bt0 = H.bt0; D.cs = H.cs; D.G = c->lazy ? c->d_rows : H.G; D.ymean = 0; D.varY = 0; D.N = H.N; D.nte = H.nte;
+        D.lazy = c->lazy; D.pool_rows = c->pool_rows; D.pool_base = f * c->pool_rows;
+        D.slot_of = c->lazy ? c->d_lazy + c->lazy_hdr + (size_t)f * KF : nullptr;
+        D.pool_next = c->lazy ? c->d_lazy + f : nullptr;
     }
     CK(dmalloc(&c->d_folds, (size_t)n_folds));
     CK(hipMemcpy(c->d_folds, fd.data(), sizeof(FoldDev) * n_folds, hipMemcpyHostToDevice));
@@ -614,6 +663,10 @@ static int prepare_folds(pareben_ctx *c)
         // ymean / varY live inside the FoldDev record: copy the two doubles device-to-device
         HIPCHK(hipMemcpyAsync((char *)(c->d_folds + f) + offsetof(FoldDev, ymean), H.ystat, 2 * sizeof(double),
                               hipMemcpyDeviceToDevice, c->stream));
+    }
+    if (c->lazy) {                                 // empty row pools: every run recomputes what it needs
+        HIPCHK(hipMemsetAsync(c->d_lazy, 0, sizeof(int) * c->lazy_hdr, c->stream));
+        HIPCHK(hipMemsetAsync(c->d_lazy + c->lazy_hdr, 0xFF, sizeof(int) * (size_t)c->n_folds * kf, c->stream));
     }
     HIPCHK(hipGetLastError());
     return PAREBEN_OK;
@@ -671,6 +724,7 @@ extern "C" int pareben_ctx_run(pareben_ctx *c, int n_cells, const double *alpha,
     }
     if (occ < 1) occ = 1;
     int blocks = std::min(n_units, c->n_cu * occ);
+    if (c->lazy && blocks > c->max_blocks) blocks = c->max_blocks;
     int rc = ensure_workspace(c, blocks);
     if (rc) return rc;
 
@@ -706,6 +760,7 @@ extern "C" int pareben_ctx_run(pareben_ctx *c, int n_cells, const double *alpha,
     P.fold_err = d_err; P.status = d_status; P.counters = d_cnt; P.phase = d_phase; P.ws = c->d_ws;
     P.ws_stride = c->L.bytes; P.offK = c->L.offK; P.offSig = c->L.offSig; P.offM = c->L.offM;
     P.K = c->kfull; P.cap = c->cap; P.n_folds = nF; P.n_units = n_units; P.v = c->variant;
+    P.priv_rows = c->priv_rows; P.priv_base0 = nF * c->pool_rows;
     if (binom) {
         BmCvParams Q;
         Q.folds = c->d_folds; Q.alpha = d_alpha; Q.lambda = d_lambda; Q.order = d_order; Q.queue = d_queue;

@@ -14,7 +14,12 @@ struct FoldDev {
     const double *rscale;   // K  1/scale
     const double *bt0;      // K  x_i.y / scale_i
     const double *cs;       // K  x_i.1 / scale_i
-    const double *G;        // K x K normalised Gram, row u: G[u*K+i] = x_i.(x_u/scale_u)/scale_i
+    const double *G;        // normalised Gram rows, G[r*K+i] = x_i.(x_u/scale_u)/scale_i: all K rows
+                            // (r = u), or in lazy mode a pool of pool_rows rows filled on demand
+    int *slot_of;           // lazy mode: K ints, row id of feature u (-1 absent, -2 in flight)
+    int *pool_next;         // lazy mode: slots handed out so far from this fold's pool
+    int pool_base;          // lazy mode: row id of this fold's first pool row (G is common to all folds)
+    int pool_rows, lazy;
     double ymean;           // sum(y)/N                                       MainEff.c:145-147
     double varY;            // unbiased variance of y                         MainEff.c:152
     int N, nte;
@@ -52,7 +57,10 @@ struct GmWork {
     signed char *act;                                      // K
     double *Sig, *H;                                       // cap x cap, column-major, ld = cap
     double *A, *mu, *gam, *v1, *v2, *v3, *v4;              // cap+1 each
-    int *used;                                             // cap+1
+    int *used;                                             // cap+1  feature of each active slot
+    int *rowid;                                            // cap+1  Gram row id of each active slot
+    int *pfree;                                            // lazy mode: [0] = n free, [1..] free private row ids
+    int priv_base, priv_rows;                              // this workgroup's private rows (pool exhausted)
     double *e;                                             // max(N) scratch
     int cap, ld;
 };

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstring>
 #include <cstdlib>
+#include <cstdio>
 #include <algorithm>
 #include "../../pareben_amd/csrc/types.h"
 #include "../../pareben_amd/csrc/blk.h"
@@ -59,11 +60,12 @@ FoldDev dev_view(const Fold &F)
     D.X = F.X.data(); D.y = F.y.data(); D.Xte = F.Xte.data(); D.yte = F.yte.data();
     D.scale = F.scale.data(); D.rscale = F.rscale.data(); D.bt0 = F.bt0.data(); D.cs = F.cs.data();
     D.G = F.G.data(); D.ymean = F.ymean; D.varY = F.varY; D.N = F.N; D.nte = F.nte;
+    D.slot_of = nullptr; D.pool_next = nullptr; D.pool_base = 0; D.pool_rows = 0; D.lazy = 0;
     return D;
 }
 
 struct Work {
-    std::vector<double> kd, sig, md; std::vector<int> ki, used; std::vector<signed char> act;
+    std::vector<double> kd, sig, md; std::vector<int> ki, used, rowid, pfree; std::vector<signed char> act;
     GmWork W;
     Work(int K, int cap)
     {
@@ -75,7 +77,7 @@ struct Work {
         W.Sig = sig.data(); W.H = sig.data() + (size_t)cap * cap;
         d = md.data(); int c1 = cap + 1;
         W.A = d; d += c1; W.mu = d; d += c1; W.gam = d; d += c1; W.v1 = d; d += c1; W.v2 = d; d += c1; W.v3 = d; d += c1; W.v4 = d;
-        W.used = used.data(); W.e = nullptr; W.cap = cap; W.ld = cap;
+        W.used = used.data(); rowid.assign(cap + 1, 0); W.rowid = rowid.data(); pfree.assign(cap + 2, 0); W.pfree = pfree.data(); W.priv_base = 0; W.priv_rows = 0; W.e = nullptr; W.cap = cap; W.ld = cap;
     }
 };
 }  // namespace
@@ -119,14 +121,35 @@ static int emul_gauss_grid(const double *basis_in, int n, int p_in, const double
     std::vector<Fold> folds(n_folds);
     for (int f = 0; f < n_folds; f++) prepare(folds[f], basis, n, p, y, fold_id, f);
     Work ws(p, cap);
-    Blk B; B.tid = 0; B.nthr = 1; B.lane = 0; B.wave = 0; B.nwave = 1; B.red = nullptr; B.ired = nullptr; B.pool = nullptr; B.xred = nullptr; B.pool_n = 0;
+    int ired[4];
+    Blk B; B.tid = 0; B.nthr = 1; B.lane = 0; B.wave = 0; B.nwave = 1; B.red = nullptr; B.ired = ired; B.pool = nullptr; B.xred = nullptr; B.pool_n = 0;
+    // PAREBEN_EMUL_LAZY=<rows per fold>[,<private rows>]: exercise the on-demand Gram-row pool (and the
+    // per-workgroup private rows behind it) instead of the full matrix
+    const char *lz = getenv("PAREBEN_EMUL_LAZY");
+    int pool_rows = 0, priv_rows = cap;
+    if (lz) { pool_rows = atoi(lz); if (const char *cm = strchr(lz, ',')) priv_rows = atoi(cm + 1); }
+    std::vector<double> rows;
+    std::vector<std::vector<int>> slot(n_folds);
+    std::vector<int> next(n_folds, 0);
+    if (pool_rows > 0) {
+        rows.assign(((size_t)pool_rows * n_folds + priv_rows) * p, NAN);
+        for (int f = 0; f < n_folds; f++) slot[f].assign(p, -1);
+        ws.W.priv_base = pool_rows * n_folds; ws.W.priv_rows = priv_rows;
+    }
     for (int c = 0; c < n_cells; c++)
         for (int f = 0; f < n_folds; f++) {
             FoldDev F = dev_view(folds[f]);
+            if (pool_rows > 0) { F.G = rows.data(); F.slot_of = slot[f].data(); F.pool_next = &next[f]; F.pool_base = f * pool_rows; F.pool_rows = pool_rows; F.lazy = 1; }
             GmScalars S; FitCounters cnt; S.c = &cnt; S.ph = nullptr; S.v = variant;
             gm_fit(B, F, ws.W, p, lambda[c], alpha[c], S);
             const int u = c * n_folds + f;
             fold_err[u] = gm_fold_sse(B, F, ws.W, S);
+            if (getenv("EMUL_DBG") && pool_rows > 0) {
+                int nbad = 0, nrow = 0;
+                for (int uu = 0; uu < p; uu++) { int sl = slot[f][uu]; if (sl < 0) continue; nrow++;
+                    for (int i = 0; i < p; i++) if (rows[(size_t)sl * p + i] != folds[f].G[(size_t)uu * p + i]) nbad++; }
+                fprintf(stderr, "c=%d f=%d rows=%d mismatching entries=%d M=%d\n", c, f, nrow, nbad, S.M);
+            }
             if (status) status[u] = S.status;
             if (counters) std::memcpy(counters + (size_t)u * PAREBEN_NCOUNTERS, &cnt, sizeof cnt);
         }

@@ -56,3 +56,23 @@ def test_epistasis_subgrid(golden):
     sel2 = [0, 399]
     E2, st2, _ = emul_lib.cv_grid(X, golden.y[:200], g["fold_id"], 5, g["alpha"][sel2], g["lam"][sel2], epis=True)
     assert (np.abs(E2 - g["fold_err"][sel2]) / g["fold_err"][sel2]).max() < 1e-10
+
+
+def test_lazy_gram_rows_match_full_matrix(golden, monkeypatch):
+    """On-demand Gram-row pool (gm_row) vs the precomputed matrix: identical bits and counters; a
+    pool smaller than a fit's active set flags the fit instead of returning a wrong score."""
+    g = golden.config1
+    X, y = golden.BASIS[:50, :100], golden.y[:50]
+    sel = np.arange(0, 400, 25)
+    E0, st0, c0 = emul_lib.cv_grid(X, y, g["fold_id"], 3, g["alpha"][sel], g["lam"][sel])
+    monkeypatch.setenv("PAREBEN_EMUL_LAZY", "60")
+    E1, st1, c1 = emul_lib.cv_grid(X, y, g["fold_id"], 3, g["alpha"][sel], g["lam"][sel])
+    assert np.array_equal(E0, E1) and np.array_equal(st0, st1) and np.array_equal(c0, c1)
+    monkeypatch.setenv("PAREBEN_EMUL_LAZY", "3")       # pool runs out: rows go to the fit's private rows
+    E2, st2, c2 = emul_lib.cv_grid(X, y, g["fold_id"], 3, g["alpha"][sel], g["lam"][sel])
+    assert np.array_equal(E0, E2) and np.array_equal(st0, st2) and np.array_equal(c0, c2)
+    monkeypatch.setenv("PAREBEN_EMUL_LAZY", "3,2")     # ... and with too few of those the fit is flagged
+    E3, st3, _ = emul_lib.cv_grid(X, y, g["fold_id"], 3, g["alpha"][sel], g["lam"][sel])
+    starved = (st3 & 9) == 9                          # overflow + abort
+    assert starved.any() and not starved.all()
+    assert np.array_equal(E3[~starved], E0[~starved])

@@ -201,3 +201,59 @@ def test_epistasis_vs_golden(golden):
     ref = g["fold_err_scaled"]
     assert ok.mean() > 0.3                            # capacity 2K = 120 is hit by the small-lambda cells
     assert _rel(E2[ok], ref[ok]).max() < 1e-8
+
+
+def test_lazy_gram_rows_vs_full_matrix_and_golden(golden, monkeypatch):
+    """Large-p mode (per-fold K x K Gram matrices do not fit): Gram rows are computed on first use
+    into a per-fold pool shared by all workgroups (gm_row).  Forced here at small sizes:
+      * 1200 fits on 3 folds -> every workgroup races for the same few rows of 3 pools;
+      * same scores as the golden table, same counters as the full-matrix mode;
+      * a second run (pools emptied and refilled in a different order) is bit-identical."""
+    X, y = golden.BASIS[:50, :100], golden.y[:50]
+    g = golden.config1
+    with pareben_amd.Context(X, y, g["fold_id"], 3) as ctx:
+        Ef, stf, cf = ctx.run(g["alpha"], g["lam"])
+    monkeypatch.setenv("PAREBEN_GRAM_ROWS", "100")
+    with pareben_amd.Context(X, y, g["fold_id"], 3) as ctx:
+        El, stl, cl = ctx.run(g["alpha"], g["lam"])
+        order = np.random.default_rng(3).permutation(400)
+        El2, stl2, _ = ctx.run(g["alpha"][order], g["lam"][order])
+    assert _rel(El, g["fold_err"]).max() < REL_FOLD
+    assert np.array_equal(stl, stf) and np.array_equal(cl[..., :10], cf[..., :10])
+    assert np.array_equal(El2, El[order]) and np.array_equal(stl2, stl[order])
+
+
+def test_lazy_gram_rows_larger_synthetic(oracle, monkeypatch):
+    """p = 3000 with a pool of 600 rows per fold: the grid touches far more than 600 features per
+    fold, so most rows end up in the workgroups' private rows (recomputed per fit, as the reference
+    does) while the pool serves the popular ones.  Compared with the full-matrix mode and the oracle."""
+    X, y = synthetic_gaussian(400, 3000, n_causal=15, seed=77)
+    fid = AssignToFolds(X, 4)
+    alpha, lam = BuildGrid(X, y, 4)
+    sel = np.arange(3, 400, 4)
+    with pareben_amd.Context(X, y, fid, 4) as ctx:
+        Ef, stf, cf = ctx.run(alpha[sel], lam[sel])
+    for rows in ("3000", "600"):
+        monkeypatch.setenv("PAREBEN_GRAM_ROWS", rows)
+        with pareben_amd.Context(X, y, fid, 4) as ctx:
+            El, stl, cl = ctx.run(alpha[sel], lam[sel])
+        assert np.array_equal(stl, stf) and np.all(stl & 8 == 0)
+        assert _rel(El, Ef).max() < 1e-8
+        assert np.array_equal(cl[..., :6], cf[..., :6])
+    spot = [0, 50, 99]
+    Eo, _, rc = oracle.cv_grid(X, y, fid, 4, alpha[sel][spot], lam[sel][spot], n_threads=8)
+    assert rc == 0 and _rel(El[spot], Eo).max() < 1e-8
+
+
+def test_lazy_gram_rows_epistasis(golden, monkeypatch):
+    """Epistasis on the expanded design (1830 columns) through the row pool."""
+    X = golden.BASIS[:200, :60]
+    g = golden.config4
+    with pareben_amd.Context(X, g["y_scaled"], g["fold_id"], 5, epis=True) as ctx:
+        Ef, stf, _ = ctx.run(g["alpha_scaled"], g["lam_scaled"])
+    monkeypatch.setenv("PAREBEN_GRAM_ROWS", "700")
+    with pareben_amd.Context(X, g["y_scaled"], g["fold_id"], 5, epis=True) as ctx:
+        El, stl, _ = ctx.run(g["alpha_scaled"], g["lam_scaled"])
+    assert np.array_equal(stl, stf)
+    ok = (stl & 8) == 0
+    assert _rel(El[ok], Ef[ok]).max() < 1e-8
