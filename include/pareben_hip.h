@@ -17,6 +17,12 @@
  *   pareben_fit_gaussian                .C("elasticNetLinearNeMainEff", ...) in
  *                                       EBEN_orig/R/EBelasticNet.Gaussian.R:39-51, i.e.
  *                                       EBEN_orig/src/elasticNetLinearNeMainEff.c:55
+ *   pareben_fit_gaussian_epis           .C("elasticNetLinearNeEpisEff", ...) in
+ *                                       EBEN_orig/R/EBelasticNet.Gaussian.R:16-28, i.e.
+ *                                       EBEN_orig/src/elasticNetLinearNeFull2.c:57
+ *   pareben_fit_binomial                .C("ElasticNetBinaryNEmainEff", ...) in
+ *                                       EBEN_orig/R/EBelasticNet.Binomial.R:32-46, i.e.
+ *                                       EBEN_orig/src/ElasticNetBinaryNEmainEff.c:236
  */
 #ifndef PAREBEN_HIP_H
 #define PAREBEN_HIP_H
@@ -108,6 +114,25 @@ int pareben_cv_grid(const double *basis, int n, int p, const double *target,
 int pareben_fit_gaussian(const double *basis, const double *target, double lambda, double alpha,
                          double *Beta, double *wald, double *intercept, int n, int k,
                          int verbose, double *residual, int device, int64_t *counters);
+
+/*
+ * Same for Epis = "yes" (EBEN_orig/R/EBelasticNet.Gaussian.R:16-28): Beta is k(k+1)/2 x 5
+ * column-major (loc1, loc2, beta, posterior variance, 1-based column id where used); rows are the k
+ * main effects followed by the pairs (1,2),(1,3)..(k-1,k) (elasticNetLinearNeFull2.c:115-134).
+ */
+int pareben_fit_gaussian_epis(const double *basis, const double *target, double lambda, double alpha,
+                              double *Beta, double *wald, double *intercept, int n, int k,
+                              int verbose, double *residual, int device, int64_t *counters);
+
+/*
+ * One binomial fit on all rows, same argument tuple as the reference's .C entry
+ * (EBEN_orig/R/EBelasticNet.Binomial.R:32-46): Beta is k x 4 column-major, intercept[0] = posterior
+ * mean of the intercept, intercept[1] = its posterior variance (ElasticNetBinaryNEmainEff.c:374-375).
+ * bMax is accepted for signature compatibility; the active-set capacity is min(k + 1, 1024).
+ */
+int pareben_fit_binomial(const double *basis, const double *target, double lambda, double alpha,
+                         double *logLikelihood, double *Beta, double *wald, double *intercept,
+                         int n, int k, int verbose, int bMax, int device, int64_t *counters);
 
 #ifdef __cplusplus
 }

@@ -14,9 +14,20 @@
 
 static inline double dot_seq(int n, const double *a, const double *b)
 {
+#ifdef EBEN_BLAS_ORDER_UNROLL4
+    /* Sensitivity experiment only (liboracle_blas4.so): the accumulation order of an optimised
+     * BLAS ddot (four running partial sums) instead of netlib's single one -- what the
+     * reference computes when R is linked against such a BLAS.  Never used as the checker. */
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    int i = 0;
+    for (; i + 3 < n; i += 4) { s0 += a[i] * b[i]; s1 += a[i + 1] * b[i + 1]; s2 += a[i + 2] * b[i + 2]; s3 += a[i + 3] * b[i + 3]; }
+    for (; i < n; i++) s0 += a[i] * b[i];
+    return (s0 + s1) + (s2 + s3);
+#else
     double s = 0;
     for (int i = 0; i < n; i++) s = s + a[i] * b[i];
     return s;
+#endif
 }
 
 /* unbiased variance: elasticNetLinearNeMainEff.c:1826-1838 (same routine in every kernel) */

@@ -39,6 +39,8 @@ def load():
     L.pareben_ctx_destroy.argtypes = [C.c_void_p]
     L.pareben_cv_grid.argtypes = [dp, C.c_int, C.c_int, dp, ip, C.c_int, dp, dp, C.c_int, C.c_int, C.c_int, C.c_int, dp, ip, lp]
     L.pareben_fit_gaussian.argtypes = [dp, dp, C.c_double, C.c_double, dp, dp, dp, C.c_int, C.c_int, C.c_int, dp, C.c_int, lp]
+    L.pareben_fit_gaussian_epis.argtypes = L.pareben_fit_gaussian.argtypes
+    L.pareben_fit_binomial.argtypes = [dp, dp, C.c_double, C.c_double, dp, dp, dp, dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, lp]
     _lib = L
     return L
 
@@ -117,17 +119,36 @@ class Context:
             pass
 
 
-def fit_gaussian(BASIS, Target, lam, alpha, device=0):
-    """Mirror of the reference's .C("elasticNetLinearNeMainEff") tuple
-    (EBEN_orig/R/EBelasticNet.Gaussian.R:39-51) -> dict(Beta K x 4, wald, intercept, residual, counters)."""
+def fit_gaussian(BASIS, Target, lam, alpha, device=0, epis=False):
+    """Mirror of the reference's .C("elasticNetLinearNeMainEff") / .C("elasticNetLinearNeEpisEff") tuples
+    (EBEN_orig/R/EBelasticNet.Gaussian.R:16-51) -> dict(Beta K x 4 | K(K+1)/2 x 5, wald, intercept,
+    residual, counters)."""
+    L = load()
+    X = np.asfortranarray(BASIS, dtype=np.float64)
+    y = np.ascontiguousarray(Target, dtype=np.float64).reshape(-1)
+    n, k = X.shape
+    Beta = np.zeros((k * (k + 1) // 2, 5), order="F") if epis else np.zeros((k, 4), order="F")
+    wald, icpt, resid = C.c_double(0), C.c_double(0), C.c_double(0)
+    cnt = np.zeros(NCOUNTERS, dtype=np.int64)
+    fn, name = (L.pareben_fit_gaussian_epis, "pareben_fit_gaussian_epis") if epis else (L.pareben_fit_gaussian, "pareben_fit_gaussian")
+    _chk(fn(_dp(X), _dp(y), float(lam), float(alpha), _dp(Beta), C.byref(wald), C.byref(icpt),
+            n, k, 0, C.byref(resid), int(device), _lp(cnt)), name)
+    return dict(Beta=Beta, wald=wald.value, intercept=icpt.value, residual=resid.value,
+                counters=dict(zip(COUNTER_NAMES, (int(v) for v in cnt))))
+
+
+def fit_binomial(BASIS, Target, lam, alpha, device=0):
+    """Mirror of the reference's .C("ElasticNetBinaryNEmainEff") tuple (EBEN_orig/R/EBelasticNet.Binomial.R:32-46)
+    -> dict(Beta K x 4, logLikelihood, wald, intercept[2] = (mu0, Sigma00), counters)."""
     L = load()
     X = np.asfortranarray(BASIS, dtype=np.float64)
     y = np.ascontiguousarray(Target, dtype=np.float64).reshape(-1)
     n, k = X.shape
     Beta = np.zeros((k, 4), order="F")
-    wald, icpt, resid = C.c_double(0), C.c_double(0), C.c_double(0)
+    ll, wald = C.c_double(0), C.c_double(0)
+    icpt = np.zeros(2)
     cnt = np.zeros(NCOUNTERS, dtype=np.int64)
-    _chk(L.pareben_fit_gaussian(_dp(X), _dp(y), float(lam), float(alpha), _dp(Beta), C.byref(wald), C.byref(icpt),
-                                n, k, 0, C.byref(resid), int(device), _lp(cnt)), "pareben_fit_gaussian")
-    return dict(Beta=Beta, wald=wald.value, intercept=icpt.value, residual=resid.value,
+    _chk(L.pareben_fit_binomial(_dp(X), _dp(y), float(lam), float(alpha), C.byref(ll), _dp(Beta), C.byref(wald), _dp(icpt),
+                                n, k, 0, k, int(device), _lp(cnt)), "pareben_fit_binomial")
+    return dict(Beta=Beta, logLikelihood=ll.value, wald=wald.value, intercept=icpt,
                 counters=dict(zip(COUNTER_NAMES, (int(v) for v in cnt))))

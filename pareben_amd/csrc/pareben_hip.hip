@@ -409,28 +409,40 @@ __global__ __launch_bounds__(FIT_THREADS) void bm_cv_kernel(BmCvParams P)
 struct FitParams {
     FoldDev F;
     double lambda, alpha;
-    double *Beta;        // K x 4
+    double *Beta;        // K x 4 (main effects) or K x 5 (epistasis, K = p(p+1)/2)
     double *scalars;     // wald, intercept, residual
     int *status;
     long long *counters;
     char *ws;
     size_t offK, offSig, offM;
     int K, cap;
+    int p;               // design columns (K = p without epistasis)
+    GmVariant v;
 };
 
-// single fit with the reference's .C outputs (elasticNetLinearNeMainEff.c:199-227)
+// single Gaussian fit with the reference's .C outputs: elasticNetLinearNeMainEff.c:199-227 (Beta K x 4:
+// locus, locus, effect, posterior variance) or elasticNetLinearNeFull2.c:115-134, :232-238 (Beta
+// M_full x 5: locus1, locus2, effect, variance, 1-based column id of used columns)
 __global__ __launch_bounds__(FIT_THREADS) void gm_fit_kernel(FitParams P)
 {
     __shared__ FitCounters s_cnt;
     __shared__ long long s_ph[8];
     const Blk B = make_blk();
     const GmWork W = ws_carve(P.ws, P.K, P.cap, P.offK, P.offSig, P.offM);
-    const int K = P.K;
-    PAR(i, K) { P.Beta[i] = i + 1; P.Beta[K + i] = i + 1; P.Beta[2 * (size_t)K + i] = 0; P.Beta[3 * (size_t)K + i] = 0; }
+    const int K = P.K, p = P.p;
+    const int ncol = P.v.epis ? 5 : 4;
+    PAR(i, p) { P.Beta[i] = i + 1; P.Beta[(size_t)K + i] = i + 1; }
+    if (P.v.epis) {
+        PAR(i, p - 1) {                                       // pairs (i, j > i) follow the main effects
+            size_t kk = (size_t)p + (size_t)i * (2 * (size_t)p - i - 1) / 2;
+            for (int j = i + 1; j < p; j++, kk++) { P.Beta[kk] = i + 1; P.Beta[(size_t)K + kk] = j + 1; }
+        }
+    }
+    for (int c = 2; c < ncol; c++) PAR(i, K) P.Beta[(size_t)c * K + i] = 0;
     GmScalars S;
     S.c = &s_cnt;
     S.ph = s_ph;
-    S.v = GmVariant{0, 0.9, 0.001, 1e-3, 1e2, 1e-10};
+    S.v = P.v;
     gm_fit(B, P.F, W, K, P.lambda, P.alpha, S);
     const int M = S.M, ld = W.ld;
     PAR(i, M) {
@@ -438,6 +450,7 @@ __global__ __launch_bounds__(FIT_THREADS) void gm_fit_kernel(FitParams P)
         const double sc = P.F.scale[f];
         P.Beta[2 * (size_t)K + f] = W.mu[i] / sc;
         P.Beta[3 * (size_t)K + f] = W.Sig[(size_t)i * ld + i] / (sc * sc);
+        if (P.v.epis) P.Beta[4 * (size_t)K + f] = f + 1;
     }
     // Wald score mu' H mu with the H of the last final update (:199-215)
     double part = 0;
@@ -451,6 +464,55 @@ __global__ __launch_bounds__(FIT_THREADS) void gm_fit_kernel(FitParams P)
         P.scalars[0] = wald;
         P.scalars[1] = S.b;
         P.scalars[2] = 1 / (S.beta + 1e-10);
+        P.status[0] = S.status;
+        if (P.counters) store_counters(P.counters, s_cnt);
+    }
+}
+
+struct BmFitParams {
+    FoldDev F;
+    double lambda, alpha;
+    double *Beta;        // K x 4
+    double *scalars;     // logLikelihood, wald, intercept, Sigma[0,0]
+    int *status;
+    long long *counters;
+    char *ws;
+    BmLayout L;
+    int K;
+};
+
+// single binomial fit with the reference's .C outputs (ElasticNetBinaryNEmainEff.c:346-389)
+__global__ __launch_bounds__(FIT_THREADS) void bm_fit_kernel(BmFitParams P)
+{
+    __shared__ FitCounters s_cnt;
+    __shared__ long long s_ph[8];
+    const Blk B = make_blk();
+    const BmWork W = bm_carve(P.ws, P.K, P.L);
+    const int K = P.K;
+    PAR(i, K) { P.Beta[i] = i + 1; P.Beta[(size_t)K + i] = i + 1; P.Beta[2 * (size_t)K + i] = 0; P.Beta[3 * (size_t)K + i] = 0; }
+    GmScalars S;
+    S.c = &s_cnt; S.ph = s_ph;
+    double ll;
+    bm_fit(B, P.F, W, K, P.lambda, P.alpha, S, &ll);
+    const int M = S.M, ld = W.ld;
+    for (int i = 1 + threadIdx.x; i < M; i += blockDim.x) {
+        const int f = W.used[i - 1];
+        const double sc = P.F.scale[f];
+        P.Beta[2 * (size_t)K + f] = W.mu[i] / sc;
+        P.Beta[3 * (size_t)K + f] = W.Sig[(size_t)i * ld + i] / (sc * sc);
+    }
+    double part = 0;
+    PAR(i, M) {
+        double a = 0;
+        for (int j = 0; j < M; j++) a += W.H[(size_t)i * ld + j] * W.mu[j];
+        part += a * W.mu[i];
+    }
+    const double wald = blk_sum(B, part);
+    if (threadIdx.x == 0) {
+        P.scalars[0] = ll;
+        P.scalars[1] = wald;
+        P.scalars[2] = W.mu[0];
+        P.scalars[3] = W.Sig[0];
         P.status[0] = S.status;
         if (P.counters) store_counters(P.counters, s_cnt);
     }
@@ -825,18 +887,15 @@ extern "C" int pareben_cv_grid(const double *basis, int n, int p, const double *
     return rc;
 }
 
-extern "C" int pareben_fit_gaussian(const double *basis, const double *target, double lambda, double alpha,
-                                    double *Beta, double *wald, double *intercept, int n, int k,
-                                    int verbose, double *residual, int device, int64_t *counters)
+// one fit on all rows: a pseudo-fold whose training set is every row and whose held-out set is empty
+static int fit_one(int prior, int epis, const double *basis, const double *target, double lambda, double alpha,
+                   int n, int k, int device, double *Beta, double *scalars_out, int n_scalars, int64_t *counters)
 {
-    (void)verbose;
-    if (!basis || !target || !Beta || !wald || !intercept || !residual || n < 2 || k < 1) return fail(PAREBEN_EINVAL, "bad argument");
-    // one pseudo-fold whose training set is every row and whose held-out set is empty
     std::vector<std::vector<int>> tr(1), te(1);
     tr[0].resize(n);
     std::iota(tr[0].begin(), tr[0].end(), 0);
     pareben_ctx *c = nullptr;
-    int rc = ctx_create_impl(&c, device, basis, n, k, target, tr, te, PAREBEN_PRIOR_GAUSSIAN, 0, 0);
+    int rc = ctx_create_impl(&c, device, basis, n, k, target, tr, te, prior, epis, 0);
     if (rc) return rc;
     auto bail = [&](int code) { pareben_ctx_destroy(c); return code; };
     if (hipSetDevice(c->device) != hipSuccess) return bail(fail(PAREBEN_EHIP, "hipSetDevice"));
@@ -844,28 +903,77 @@ extern "C" int pareben_fit_gaussian(const double *basis, const double *target, d
     if (rc) return bail(rc);
     rc = ensure_workspace(c, 1);
     if (rc) return bail(rc);
+    const size_t KF = (size_t)c->kfull;
+    const int ncol = epis ? 5 : 4;
     double *d_beta = nullptr, *d_sc = nullptr; int *d_st = nullptr; long long *d_cnt = nullptr;
     auto cleanup = [&]() { hipFree(d_beta); hipFree(d_sc); hipFree(d_st); hipFree(d_cnt); };
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return bail(fail(PAREBEN_EHIP, #x, e_)); } } while (0)
-    CK(dmalloc(&d_beta, (size_t)k * 4)); CK(dmalloc(&d_sc, (size_t)3)); CK(dmalloc(&d_st, (size_t)1));
+    CK(dmalloc(&d_beta, KF * ncol)); CK(dmalloc(&d_sc, (size_t)4)); CK(dmalloc(&d_st, (size_t)1));
     CK(dmalloc(&d_cnt, (size_t)PAREBEN_NCOUNTERS));
     CK(hipStreamSynchronize(c->stream));
-    FitParams P;
-    CK(hipMemcpy(&P.F, c->d_folds, sizeof(FoldDev), hipMemcpyDeviceToHost));
-    P.lambda = lambda; P.alpha = alpha; P.Beta = d_beta; P.scalars = d_sc; P.status = d_st; P.counters = d_cnt;
-    P.ws = c->d_ws; P.offK = c->L.offK; P.offSig = c->L.offSig; P.offM = c->L.offM; P.K = k; P.cap = c->cap;
-    CK(hipFuncSetAttribute((const void *)gm_fit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FIT_BYTES));
-    hipLaunchKernelGGL(gm_fit_kernel, dim3(1), dim3(FIT_THREADS), LDS_FIT_BYTES, c->stream, P);
+    FoldDev F;
+    CK(hipMemcpy(&F, c->d_folds, sizeof(FoldDev), hipMemcpyDeviceToHost));
+    if (prior == PAREBEN_PRIOR_GAUSSIAN) {
+        FitParams P;
+        P.F = F; P.lambda = lambda; P.alpha = alpha; P.Beta = d_beta; P.scalars = d_sc; P.status = d_st; P.counters = d_cnt;
+        P.ws = c->d_ws; P.offK = c->L.offK; P.offSig = c->L.offSig; P.offM = c->L.offM; P.K = c->kfull; P.cap = c->cap;
+        P.p = k; P.v = c->variant;
+        CK(hipFuncSetAttribute((const void *)gm_fit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FIT_BYTES));
+        hipLaunchKernelGGL(gm_fit_kernel, dim3(1), dim3(FIT_THREADS), LDS_FIT_BYTES, c->stream, P);
+    } else {
+        BmFitParams P;
+        P.F = F; P.lambda = lambda; P.alpha = alpha; P.Beta = d_beta; P.scalars = d_sc; P.status = d_st; P.counters = d_cnt;
+        P.ws = c->d_ws; P.L = c->BL; P.K = k;
+        CK(hipFuncSetAttribute((const void *)bm_fit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FIT_BYTES));
+        hipLaunchKernelGGL(bm_fit_kernel, dim3(1), dim3(FIT_THREADS), LDS_FIT_BYTES, c->stream, P);
+    }
     CK(hipGetLastError());
     CK(hipStreamSynchronize(c->stream));
-    double sc[3]; int st = 0;
-    CK(hipMemcpy(Beta, d_beta, sizeof(double) * (size_t)k * 4, hipMemcpyDeviceToHost));
+    double sc[4]; int st = 0;
+    CK(hipMemcpy(Beta, d_beta, sizeof(double) * KF * ncol, hipMemcpyDeviceToHost));
     CK(hipMemcpy(sc, d_sc, sizeof sc, hipMemcpyDeviceToHost));
     CK(hipMemcpy(&st, d_st, sizeof st, hipMemcpyDeviceToHost));
     if (counters) CK(hipMemcpy(counters, d_cnt, sizeof(int64_t) * PAREBEN_NCOUNTERS, hipMemcpyDeviceToHost));
 #undef CK
-    *wald = sc[0]; *intercept = sc[1]; *residual = sc[2];
+    for (int i = 0; i < n_scalars; i++) scalars_out[i] = sc[i];
     cleanup();
     pareben_ctx_destroy(c);
     return (st & ST_ABORT) ? fail(PAREBEN_EHIP, "fit aborted (see status bits in counters[11])") : PAREBEN_OK;
+}
+
+extern "C" int pareben_fit_gaussian(const double *basis, const double *target, double lambda, double alpha,
+                                    double *Beta, double *wald, double *intercept, int n, int k,
+                                    int verbose, double *residual, int device, int64_t *counters)
+{
+    (void)verbose;
+    if (!basis || !target || !Beta || !wald || !intercept || !residual || n < 2 || k < 1) return fail(PAREBEN_EINVAL, "bad argument");
+    double sc[3];
+    const int rc = fit_one(PAREBEN_PRIOR_GAUSSIAN, 0, basis, target, lambda, alpha, n, k, device, Beta, sc, 3, counters);
+    if (rc == PAREBEN_OK) { *wald = sc[0]; *intercept = sc[1]; *residual = sc[2]; }
+    return rc;
+}
+
+extern "C" int pareben_fit_gaussian_epis(const double *basis, const double *target, double lambda, double alpha,
+                                         double *Beta, double *wald, double *intercept, int n, int k,
+                                         int verbose, double *residual, int device, int64_t *counters)
+{
+    (void)verbose;
+    if (!basis || !target || !Beta || !wald || !intercept || !residual || n < 2 || k < 2) return fail(PAREBEN_EINVAL, "bad argument");
+    if ((long long)k * (k + 1) / 2 > 2000000000LL) return fail(PAREBEN_EINVAL, "too many pairwise columns");
+    double sc[3];
+    const int rc = fit_one(PAREBEN_PRIOR_GAUSSIAN, 1, basis, target, lambda, alpha, n, k, device, Beta, sc, 3, counters);
+    if (rc == PAREBEN_OK) { *wald = sc[0]; *intercept = sc[1]; *residual = sc[2]; }
+    return rc;
+}
+
+extern "C" int pareben_fit_binomial(const double *basis, const double *target, double lambda, double alpha,
+                                    double *logLikelihood, double *Beta, double *wald, double *intercept,
+                                    int n, int k, int verbose, int bMax, int device, int64_t *counters)
+{
+    (void)verbose; (void)bMax;
+    if (!basis || !target || !Beta || !wald || !intercept || !logLikelihood || n < 2 || k < 1) return fail(PAREBEN_EINVAL, "bad argument");
+    double sc[4];
+    const int rc = fit_one(PAREBEN_PRIOR_BINOMIAL, 0, basis, target, lambda, alpha, n, k, device, Beta, sc, 4, counters);
+    if (rc == PAREBEN_OK) { *logLikelihood = sc[0]; *wald = sc[1]; intercept[0] = sc[2]; intercept[1] = sc[3]; }
+    return rc;
 }

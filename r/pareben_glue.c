@@ -58,3 +58,44 @@ SEXP pareben_fit_gaussian_R(SEXP basis, SEXP target, SEXP lambda, SEXP alpha, SE
     UNPROTECT(3);
     return out;
 }
+
+/* drop-in for .C("elasticNetLinearNeEpisEff", ...) (EBEN_orig/R/EBelasticNet.Gaussian.R:16-28): Beta K(K+1)/2 x 5 */
+SEXP pareben_fit_gaussian_epis_R(SEXP basis, SEXP target, SEXP lambda, SEXP alpha, SEXP device)
+{
+    const int n = nrows(basis), k = ncols(basis);
+    SEXP beta = PROTECT(allocMatrix(REALSXP, k * (k + 1) / 2, 5));
+    double wald = 0, icpt = 0, resid = 0;
+    const int rc = pareben_fit_gaussian_epis(REAL(basis), REAL(target), asReal(lambda), asReal(alpha), REAL(beta),
+                                             &wald, &icpt, n, k, 0, &resid, asInteger(device), NULL);
+    if (rc != PAREBEN_OK) { UNPROTECT(1); error("pareben_fit_gaussian_epis failed (%d): %s", rc, pareben_last_error()); }
+    SEXP out = PROTECT(allocVector(VECSXP, 4));
+    SET_VECTOR_ELT(out, 0, beta);
+    SET_VECTOR_ELT(out, 1, ScalarReal(wald)); SET_VECTOR_ELT(out, 2, ScalarReal(icpt)); SET_VECTOR_ELT(out, 3, ScalarReal(resid));
+    SEXP nm = PROTECT(allocVector(STRSXP, 4));
+    SET_STRING_ELT(nm, 0, mkChar("Beta")); SET_STRING_ELT(nm, 1, mkChar("WaldScore"));
+    SET_STRING_ELT(nm, 2, mkChar("Intercept")); SET_STRING_ELT(nm, 3, mkChar("residual"));
+    setAttrib(out, R_NamesSymbol, nm);
+    UNPROTECT(3);
+    return out;
+}
+
+/* drop-in for .C("ElasticNetBinaryNEmainEff", ...) (EBEN_orig/R/EBelasticNet.Binomial.R:32-46) */
+SEXP pareben_fit_binomial_R(SEXP basis, SEXP target, SEXP lambda, SEXP alpha, SEXP device)
+{
+    const int n = nrows(basis), k = ncols(basis);
+    SEXP beta = PROTECT(allocMatrix(REALSXP, k, 4));
+    SEXP icpt = PROTECT(allocVector(REALSXP, 2));
+    double ll = 0, wald = 0;
+    const int rc = pareben_fit_binomial(REAL(basis), REAL(target), asReal(lambda), asReal(alpha), &ll, REAL(beta),
+                                        &wald, REAL(icpt), n, k, 0, k, asInteger(device), NULL);
+    if (rc != PAREBEN_OK) { UNPROTECT(2); error("pareben_fit_binomial failed (%d): %s", rc, pareben_last_error()); }
+    SEXP out = PROTECT(allocVector(VECSXP, 4));
+    SET_VECTOR_ELT(out, 0, beta);
+    SET_VECTOR_ELT(out, 1, ScalarReal(ll)); SET_VECTOR_ELT(out, 2, ScalarReal(wald)); SET_VECTOR_ELT(out, 3, icpt);
+    SEXP nm = PROTECT(allocVector(STRSXP, 4));
+    SET_STRING_ELT(nm, 0, mkChar("Beta")); SET_STRING_ELT(nm, 1, mkChar("logLikelihood"));
+    SET_STRING_ELT(nm, 2, mkChar("WaldScore")); SET_STRING_ELT(nm, 3, mkChar("Intercept"));
+    setAttrib(out, R_NamesSymbol, nm);
+    UNPROTECT(4);
+    return out;
+}

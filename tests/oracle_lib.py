@@ -27,7 +27,7 @@ def build():
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_ORACLE_DIR, "liboracle.so")
+        path = os.environ.get("EBEN_ORACLE_LIB") or os.path.join(_ORACLE_DIR, "liboracle.so")
         if not os.path.exists(path):
             build()
         _LIB = C.CDLL(path)
