@@ -97,22 +97,29 @@ template <class T> DEV T *uni_ptr(T *p)
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return (T *)(((unsigned long long)hi << 32) | lo);
 }
-#define FS_JTW 2          // row tiles per wave and pass (each against 4 feature sub-tiles)
+#define FS_JTW 2          // row tiles per wave and pass
 #define FS_PC 16          // Gram rows staged per chunk (= one k-block)
-#define FS_LD 80          // LDS row pitch in doubles (64 + 16: conflict-free b64 reads)
-#define FS_SR 4           // staged rows per wave and chunk (FS_PC / 8 waves at least)
-#define FS_PF 4           // Sigma-operand prefetch distance in k-steps (divides FS_PC / 4)
+#ifndef FS_FT
+#define FS_FT 128         // features per tile: Sigma operands are streamed once per FS_FT features
+#endif
+#define FS_NU (FS_FT / 16)   // 16-feature sub-tiles per tile (each Sigma operand feeds FS_NU matrix ops)
+#define FS_NH (FS_FT / 64)   // 64-lane halves of a staged Gram row
+#define FS_LD (FS_FT + 16)   // LDS row pitch in doubles (conflict-free b64 reads)
 #ifndef FS_NWAVES
 #define FS_NWAVES 16      // wavefronts per fit workgroup (set by the kernel file from FIT_THREADS)
 #endif
+#ifndef FS_AD
+#define FS_AD 2           // register-ring depth: Sigma operands are fetched FS_AD - 1 k-blocks ahead
+#endif
 
-// One 16-row k-block (4 k-steps) for the row tiles in MASK (bit 0: tile 0, bit 1: tile 1) against the
-// four 16-feature sub-tiles of the staged Gram block.  Everything that comes from beyond L2 is
-// fetched TWO k-blocks ahead into three-slot register rings indexed at compile time (CUR = h mod 3):
-// block h consumes slot CUR, issues the loads of block h+2 into slot CUR+2 and writes the Gram rows
-// of block h+1 (slot CUR+1, loaded during block h-1) to LDS.  No register copies and no branch
+// One 16-row k-block (4 k-steps) for two row tiles against the FS_NU 16-feature sub-tiles of the
+// staged Gram block.  Everything that comes from beyond L2 is fetched ahead into register rings
+// indexed at compile time (CUR = h mod FS_AD): block h consumes Sigma slot CUR and issues the Sigma
+// loads of block h + FS_AD - 1; Gram rows of block h + 2 are requested into their ring and those of
+// block h + 1 (requested during block h - 1) are written to LDS.  No register copies and no branch
 // between a load and its use: the compiler keeps counted s_waitcnt vmcnt(N) and the loads stay in
-// flight across two blocks of MFMAs and two barriers.
+// flight across blocks of matrix ops and barriers.  (The function must not spill: a scratch reload
+// pending at loop entry turns into a static s_waitcnt vmcnt(0) inside the loop.)
 //   w0 / w1: 2.0 while THIS k-block is strictly below the tile's diagonal block, 1.0 on it
 //   (Sigma is symmetric: row tile J only visits k-blocks P <= J and counts P < J twice; doubling an
 //   operand is exact).
@@ -123,44 +130,52 @@ template <class T> DEV T *uni_ptr(T *p)
 template <int CUR>
 DEV void fs_kblock(gptr_cd Sig, gptr_cd G, lptr_i lused, lptr_d cur, lptr_d nxt, int ld, int row_max,
                    int roff0, int roff1, int h, bool act0, bool act1, bool nxt0, bool nxt1, double w0, double w1,
-                   int M, int K, int istage, int wave, int lane, double (&a)[3][4][2], double (&sv)[3][FS_RPW],
-                   d4 (&acc)[2][4])
+                   int M, int K, const int (&istage)[FS_NH], int wave, int lane, double (&a)[FS_AD][4][2],
+                   double (&sv)[FS_AD][FS_RPW][FS_NH], d4 (&acc)[2][FS_NU])
 {
-    constexpr int NX1 = (CUR + 1) % 3, NX2 = (CUR + 2) % 3;
+    constexpr int NX1 = (CUR + 1) % FS_AD, NX2 = (CUR + 2) % FS_AD, NXA = (CUR + FS_AD - 1) % FS_AD;
     const int l15 = lane & 15, l4 = lane >> 4;
 #pragma unroll
     for (int r = 0; r < FS_RPW; r++) {
         const int pp = (h + 2) * 16 + wave + r * FS_NWAVES;
-        sv[NX2][r] = G[(size_t)lused[pp < M ? pp : M - 1] * K + istage];
+        const gptr_cd grow = G + (size_t)lused[pp < M ? pp : M - 1] * K;
+#pragma unroll
+        for (int e = 0; e < FS_NH; e++) sv[NX2][r][e] = grow[istage[e]];
     }
     const lptr_d brow = cur + l4 * FS_LD + l15;
-    const int r0 = nxt0 ? roff0 : 0, r1 = nxt1 ? roff1 : 0;    // tile retired two blocks from now: fixed address
+    const int r0 = nxt0 ? roff0 : 0, r1 = nxt1 ? roff1 : 0;    // tile retired by then: one fixed address
 #pragma unroll
     for (int s = 0; s < 4; s++) {
-        double bv[4];
+        double bv[FS_NU];
 #pragma unroll
-        for (int u = 0; u < 4; u++) bv[u] = brow[s * 4 * FS_LD + u * 16];
+        for (int u = 0; u < FS_NU; u++) bv[u] = brow[s * 4 * FS_LD + u * 16];
         {
-            const int pk = (h + 2) * 16 + s * 4 + l4;
+            const int pk = (h + FS_AD - 1) * 16 + s * 4 + l4;
             const int pc = pk < row_max ? pk : row_max;
-            a[NX2][s][0] = Sig[(unsigned)((nxt0 ? pc : 0) * ld + r0)];
-            a[NX2][s][1] = Sig[(unsigned)((nxt1 ? pc : 0) * ld + r1)];
+            a[NXA][s][0] = Sig[(unsigned)((nxt0 ? pc : 0) * ld + r0)];
+            a[NXA][s][1] = Sig[(unsigned)((nxt1 ? pc : 0) * ld + r1)];
         }
-        const double av0 = a[CUR][s][0] * w0;                  // doubled at use, not at load
-        const double av1 = a[CUR][s][1] * w1;
+        double av0 = a[CUR][s][0] * w0;                        // doubled at use, not at load
+        double av1 = a[CUR][s][1] * w1;
+        // consume both operands on every path: if the multiply sinks into the guarded MFMA group an
+        // inactive tile leaves its load pending on the back edge (static s_waitcnt vmcnt(0) next iteration)
+        asm volatile("" : "+v"(av0), "+v"(av1));
         if (act0) {
 #pragma unroll
-            for (int u = 0; u < 4; u++) acc[0][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av0, bv[u], acc[0][u], 0, 0, 0);
+            for (int u = 0; u < FS_NU; u++) acc[0][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av0, bv[u], acc[0][u], 0, 0, 0);
         }
         if (act1) {
 #pragma unroll
-            for (int u = 0; u < 4; u++) acc[1][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av1, bv[u], acc[1][u], 0, 0, 0);
+            for (int u = 0; u < FS_NU; u++) acc[1][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av1, bv[u], acc[1][u], 0, 0, 0);
         }
     }
 #pragma unroll
     for (int r = 0; r < FS_RPW; r++) {
         const int row = wave + r * FS_NWAVES, pp = (h + 1) * 16 + row;
-        if (row < 16) nxt[row * FS_LD + lane] = pp < M ? sv[NX1][r] : 0.0;
+        if (row < 16) {
+#pragma unroll
+            for (int e = 0; e < FS_NH; e++) nxt[row * FS_LD + e * 64 + lane] = pp < M ? sv[NX1][r][e] : 0.0;
+        }
     }
 }
 #endif
@@ -188,43 +203,47 @@ DEVNI void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W,
     }
 #else
     // T = Sigma * Bt on the FP64 matrix cores (v_mfma_f64_16x16x4_f64), 16 x 16 tiles of T:
-    // rows j of Sigma x features i.  A 64-feature Gram tile is staged through LDS in 32-row chunks;
-    // every wave owns up to two 16-row tiles of Sigma per pass (w and 2 NW - 1 - w: with the
+    // rows j of Sigma x features i.  An FS_FT-feature Gram tile is staged through LDS in 16-row
+    // k-blocks; every wave owns up to two 16-row tiles of Sigma per pass (w and 2 NW - 1 - w: with the
     // triangular, symmetric schedule both halves cost the same) and multiplies them against all
-    // four 16-feature sub-tiles.  quad_i = sum_j T[j][i] * Bt[j][i] is folded in the epilogue with
-    // two xor-shuffles over the four row groups of the accumulator layout.
+    // FS_NU 16-feature sub-tiles, so each Sigma operand fetched from memory feeds FS_NU matrix ops.
+    // quad_i = sum_j T[j][i] * Bt[j][i] is folded in the epilogue (per pass, into LDS) with two
+    // xor-shuffles over the four row groups of the accumulator layout.
     //   A: lane l holds A[row = l & 15][k = l >> 4];  B: lane l holds B[k = l >> 4][col = l & 15]
     //   D: register r of lane l is D[row = (l >> 4) + 4 r][col = l & 15]      (f64 layout)
     // No masking in the k-loop: Gram rows >= M are staged as zeros, so Sigma entries beyond the
     // active block (finite: the workspace is zero-initialised) contribute exactly 0; rows >= M of T
     // are never read back.
+    // B lives in memory (reference argument of a non-inlined function): take register copies once, or
+    // every use in the k-loop becomes a flat load followed by s_waitcnt vmcnt(0), draining the prefetches
+    const int lane = B.lane, wave = uni(B.wave), tid = B.tid, nthr = uni(B.nthr);
     const gptr_cd Sig = as_global(uni_ptr(W.Sig));
     const gptr_cd G = as_global(uni_ptr(F.G));
     double *pool = uni_ptr(B.pool);
     const lptr_d lt = as_lds(pool);
-    const lptr_i lused = as_lds((int *)(pool + 2 * FS_PC * FS_LD));   // active-set ids, M <= 2048
-    double *xred = uni_ptr(B.xred);
+    const lptr_i lused = as_lds((int *)(pool + 2 * FS_PC * FS_LD));   // active-set row ids, M <= 2048
+    const lptr_d qred = as_lds(pool + 2 * FS_PC * FS_LD + 1024);      // [2][NW][FS_FT] per-wave partial sums
     K = uni(K); M = uni(M);
     const int ld = uni(W.ld);
     __syncthreads();
-    for (int p = B.tid; p < M; p += B.nthr) lused[p] = W.rowid[p];
+    for (int p = tid; p < M; p += nthr) lused[p] = W.rowid[p];
     __syncthreads();
     const int NW = uni(B.nwave);
-    const int l15 = B.lane & 15, l4 = B.lane >> 4;
+    const int l15 = lane & 15, l4 = lane >> 4;
     const int nJ = (M + 15) >> 4;
     const int tiles_per_pass = NW * FS_JTW;
     const int n_pass = (nJ + tiles_per_pass - 1) / tiles_per_pass;
     const int row_max = uni(W.cap) - 1;
-    for (int i0 = 0; i0 < K; i0 += 64) {
-        const int istage = (i0 + B.lane) < K ? (i0 + B.lane) : K - 1;
-        double q_acc[4], m_acc[4];
+    for (int i0 = 0; i0 < K; i0 += FS_FT) {
+        int istage[FS_NH];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { q_acc[u] = 0; m_acc[u] = 0; }
+        for (int e = 0; e < FS_NH; e++) istage[e] = (i0 + e * 64 + lane) < K ? (i0 + e * 64 + lane) : K - 1;
+        for (int e = tid; e < 2 * NW * FS_FT; e += nthr) qred[e] = 0.0;     // visible after the barriers below
         for (int pass = 0; pass < n_pass; pass++) {
             const int jbase = pass * tiles_per_pass;
             int jts[FS_JTW], roff[FS_JTW];
-            jts[0] = jbase + B.wave;                          // w and 2 NW - 1 - w: with the triangular
-            jts[1] = jbase + 2 * NW - 1 - B.wave;             // schedule both halves cost the same
+            jts[0] = jbase + wave;                          // w and 2 NW - 1 - w: with the triangular
+            jts[1] = jbase + 2 * NW - 1 - wave;             // schedule both halves cost the same
 #pragma unroll
             for (int t = 0; t < FS_JTW; t++) {
                 const int row = jts[t] * 16 + l15;
@@ -234,46 +253,73 @@ DEVNI void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W,
             const int J0 = __builtin_amdgcn_readfirstlane(jts[0] < nJ ? jts[0] : -1);
             const int J1 = __builtin_amdgcn_readfirstlane(jts[1] < nJ ? jts[1] : -1);
             const int last_tile = (jbase + tiles_per_pass < nJ ? jbase + tiles_per_pass : nJ) - 1;
-            d4 acc[FS_JTW][4];
+            d4 acc[FS_JTW][FS_NU];
 #pragma unroll
             for (int t = 0; t < FS_JTW; t++)
 #pragma unroll
-                for (int u = 0; u < 4; u++) acc[t][u] = d4{0, 0, 0, 0};
-            double a[3][4][2], sv[3][FS_RPW];
-            {   // Sigma operands of k-blocks 0 and 1 (slots 0, 1), Gram rows of k-block 1 (slot 1)
+                for (int u = 0; u < FS_NU; u++) acc[t][u] = d4{0, 0, 0, 0};
+            double a[FS_AD][4][2], sv[FS_AD][FS_RPW][FS_NH];
+            {   // Sigma operands of k-blocks 0 .. FS_AD-2 (slots 0 ..), Gram rows of k-block 1 (slot 1)
 #pragma unroll
-                for (int sidx = 0; sidx < 4; sidx++) {
-                    const int pk0 = sidx * 4 + l4, pk1 = 16 + sidx * 4 + l4;
-                    const unsigned b0 = (unsigned)((pk0 < row_max ? pk0 : row_max) * ld);
-                    const unsigned b1 = (unsigned)((pk1 < row_max ? pk1 : row_max) * ld);
-                    a[0][sidx][0] = Sig[b0 + roff[0]]; a[0][sidx][1] = Sig[b0 + roff[1]];
-                    a[1][sidx][0] = Sig[b1 + roff[0]]; a[1][sidx][1] = Sig[b1 + roff[1]];
-                }
+                for (int blk = 0; blk < FS_AD - 1; blk++)
+#pragma unroll
+                    for (int sidx = 0; sidx < 4; sidx++) {
+                        const int pk = blk * 16 + sidx * 4 + l4;
+                        const unsigned b0 = (unsigned)((pk < row_max ? pk : row_max) * ld);
+                        a[blk][sidx][0] = Sig[b0 + roff[0]]; a[blk][sidx][1] = Sig[b0 + roff[1]];
+                    }
 #pragma unroll
                 for (int r = 0; r < FS_RPW; r++) {
-                    const int pp = 16 + B.wave + r * FS_NWAVES;
-                    sv[1][r] = G[(size_t)lused[pp < M ? pp : M - 1] * K + istage];
+                    const int pp = 16 + wave + r * FS_NWAVES;
+                    const gptr_cd grow = G + (size_t)lused[pp < M ? pp : M - 1] * K;
+#pragma unroll
+                    for (int e = 0; e < FS_NH; e++) sv[1][r][e] = grow[istage[e]];
                 }
             }
             __syncthreads();
-            for (int row = B.wave; row < 16; row += NW) lt[row * FS_LD + B.lane] = (row < M) ? G[(size_t)lused[row] * K + istage] : 0.0;
+            for (int row = wave; row < 16; row += NW) {
+                const gptr_cd grow = G + (size_t)lused[row < M ? row : M - 1] * K;
+#pragma unroll
+                for (int e = 0; e < FS_NH; e++) lt[row * FS_LD + e * 64 + lane] = (row < M) ? grow[istage[e]] : 0.0;
+            }
+            // nothing may be pending at loop entry: a load still in flight here makes the compiler put
+            // a static s_waitcnt vmcnt(0) inside the loop (it merges this state into every iteration)
+            __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0), visible to the compiler's wait tracking
             __syncthreads();
 #define FS_STEP(CURSLOT, hh)                                                                                         \
-            if ((hh) <= last_tile) {                                                                                 \
+            {                                                                                                        \
                 const int h_ = (hh);                                                                                 \
                 const lptr_d cur = lt + (h_ & 1) * (FS_PC * FS_LD);                                                  \
                 const lptr_d nxt = lt + ((h_ + 1) & 1) * (FS_PC * FS_LD);                                            \
                 const double w0 = (h_ < J0) ? 2.0 : 1.0, w1 = (h_ < J1) ? 2.0 : 1.0;                                 \
                 fs_kblock<CURSLOT>(Sig, G, lused, cur, nxt, ld, row_max, roff[0], roff[1], h_, h_ <= J0, h_ <= J1,   \
-                                   h_ + 2 <= J0, h_ + 2 <= J1, w0, w1, M, K, istage, B.wave, B.lane, a, sv, acc);   \
+                                   h_ + FS_AD - 1 <= J0, h_ + FS_AD - 1 <= J1, w0, w1, M, K, istage, wave, lane,    \
+                                   a, sv, acc);                                                                      \
                 __syncthreads();                                                                                     \
             }
-            for (int h = 0; h <= last_tile; h += 3) {
+            // whole groups of FS_AD steps without any skip path inside the loop (a skipped step would leave
+            // its predecessor's prefetch pending on the back edge: static s_waitcnt vmcnt(0)); then the tail
+            int h = 0;
+#if FS_AD == 2
+            for (; h + 1 <= last_tile; h += 2) {
+                FS_STEP(0, h)
+                FS_STEP(1, h + 1)
+            }
+            if (h <= last_tile) FS_STEP(0, h)
+#else
+            for (; h + 2 <= last_tile; h += 3) {
                 FS_STEP(0, h)
                 FS_STEP(1, h + 1)
                 FS_STEP(2, h + 2)
             }
+            if (h <= last_tile) FS_STEP(0, h)
+            if (h + 1 <= last_tile) FS_STEP(1, h + 1)
+#endif
 #undef FS_STEP
+            // epilogue of the pass: this wave's share of sum_j T[j][i] b_j[i] and sum_j b_j[i] mu_j
+            double q_acc[FS_NU], m_acc[FS_NU];
+#pragma unroll
+            for (int u = 0; u < FS_NU; u++) { q_acc[u] = 0; m_acc[u] = 0; }
 #pragma unroll
             for (int t = 0; t < FS_JTW; t++) {
                 if (jts[t] < nJ) {
@@ -284,7 +330,7 @@ DEVNI void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W,
                             const gptr_cd grow = G + (size_t)lused[j] * K;
                             const double muj = W.mu[j];
 #pragma unroll
-                            for (int u = 0; u < 4; u++) {
+                            for (int u = 0; u < FS_NU; u++) {
                                 const int ic = i0 + u * 16 + l15;
                                 const double bj = grow[ic < K ? ic : K - 1];
                                 q_acc[u] += acc[t][u][r] * bj;
@@ -294,28 +340,28 @@ DEVNI void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W,
                     }
                 }
             }
-        }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            q_acc[u] += __shfl_xor(q_acc[u], 16, 64); q_acc[u] += __shfl_xor(q_acc[u], 32, 64);
-            m_acc[u] += __shfl_xor(m_acc[u], 16, 64); m_acc[u] += __shfl_xor(m_acc[u], 32, 64);
-        }
-        __syncthreads();
-        if (B.lane < 16) {
+            for (int u = 0; u < FS_NU; u++) {
+                q_acc[u] += __shfl_xor(q_acc[u], 16, 64); q_acc[u] += __shfl_xor(q_acc[u], 32, 64);
+                m_acc[u] += __shfl_xor(m_acc[u], 16, 64); m_acc[u] += __shfl_xor(m_acc[u], 32, 64);
+            }
+            if (lane < 16) {                                 // each wave owns its slice of qred: no race
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                xred[B.wave * 64 + u * 16 + l15] = q_acc[u];
-                xred[(NW + B.wave) * 64 + u * 16 + l15] = m_acc[u];
+                for (int u = 0; u < FS_NU; u++) {
+                    qred[wave * FS_FT + u * 16 + l15] += q_acc[u];
+                    qred[(NW + wave) * FS_FT + u * 16 + l15] += m_acc[u];
+                }
             }
         }
         __syncthreads();
-        if (B.tid < 64 && i0 + B.tid < K) {
-            const int i = i0 + B.tid;
+        if (tid < FS_FT && i0 + tid < K) {
+            const int i = i0 + tid;
             double q = 0, m = 0;
-            for (int w = 0; w < NW; w++) { q += xred[w * 64 + B.tid]; m += xred[(NW + w) * 64 + B.tid]; }
+            for (int w = 0; w < NW; w++) { q += qred[w * FS_FT + tid]; m += qred[(NW + w) * FS_FT + tid]; }
             W.Sin[i] = beta - beta * q * beta;
             W.Qin[i] = beta * (W.bt[i] - m);
         }
+        __syncthreads();
     }
 #endif
     blk_sync(B);

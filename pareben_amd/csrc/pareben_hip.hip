@@ -977,3 +977,46 @@ extern "C" int pareben_fit_binomial(const double *basis, const double *target, d
     if (rc == PAREBEN_OK) { *logLikelihood = sc[0]; *wald = sc[1]; intercept[0] = sc[2]; intercept[1] = sc[3]; }
     return rc;
 }
+
+#ifdef PAREBEN_DIAG
+// ------------------------------------------------------------------------------------------
+// Diagnostic build only (-DPAREBEN_DIAG, tools/ubench/fullstat_rate.py): time the full-stat feature
+// pass alone on `blocks` workgroups, each with its own Sigma (cap x cap) and a shared M x K Gram.
+struct DiagParams { const double *G; char *ws; size_t stride, offK, offSig, offM; int K, cap, M, reps; };
+__global__ __launch_bounds__(FIT_THREADS) void diag_fullstat_kernel(DiagParams P)
+{
+    const Blk B = make_blk();
+    GmWork W = ws_carve(P.ws + (size_t)blockIdx.x * P.stride, P.K, P.cap, P.offK, P.offSig, P.offM);
+    FoldDev F{};
+    F.G = P.G;
+    for (int i = threadIdx.x; i < P.M; i += blockDim.x) { W.rowid[i] = i; W.used[i] = i; W.mu[i] = 0.001 * i; }
+    __syncthreads();
+    for (int r = 0; r < P.reps; r++) gm_fullstat_features(B, F, W, P.K, P.M, 1.0);
+}
+extern "C" int pareben_diag_fullstat(int M, int K, int blocks, int reps, double *ms_out)
+{
+    const int cap = ((M + 15) / 16) * 16 + 16;
+    WsLayout L = ws_layout(K, cap);
+    char *ws = nullptr; double *G = nullptr;
+    if (hipMalloc((void **)&ws, L.bytes * (size_t)blocks) != hipSuccess) return PAREBEN_ENOMEM;
+    if (hipMalloc((void **)&G, sizeof(double) * (size_t)M * K) != hipSuccess) return PAREBEN_ENOMEM;
+    std::vector<double> h((size_t)M * K);
+    for (size_t i = 0; i < h.size(); i++) h[i] = ((i * 2654435761u) % 1000) * 1e-3 - 0.5;
+    hipMemcpy(G, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice);
+    hipMemset(ws, 0, L.bytes * (size_t)blocks);
+    DiagParams P{G, ws, L.bytes, L.offK, L.offSig, L.offM, K, cap, M, reps};
+    hipFuncSetAttribute((const void *)diag_fullstat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FIT_BYTES);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    P.reps = 1;
+    hipLaunchKernelGGL(diag_fullstat_kernel, dim3(blocks), dim3(FIT_THREADS), LDS_FIT_BYTES, 0, P);   // warm-up
+    P.reps = reps;
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(diag_fullstat_kernel, dim3(blocks), dim3(FIT_THREADS), LDS_FIT_BYTES, 0, P);
+    hipEventRecord(e1, 0);
+    if (hipDeviceSynchronize() != hipSuccess) return PAREBEN_EHIP;
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    *ms_out = ms / reps;
+    hipFree(ws); hipFree(G); hipEventDestroy(e0); hipEventDestroy(e1);
+    return PAREBEN_OK;
+}
+#endif
