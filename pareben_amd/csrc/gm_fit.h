@@ -78,6 +78,7 @@ DEVNI void gm_refresh_out(const Blk &B, const GmWork &W, int K)
 #ifndef PAREBEN_HOST_EMUL
 // address-space-qualified views (global_load / ds_read instead of flat_load) for the hot loops
 typedef const double __attribute__((address_space(1))) *gptr_cd;
+typedef const char __attribute__((address_space(1))) *gptr_cc;
 typedef const int __attribute__((address_space(1))) *gptr_ci;
 typedef double __attribute__((address_space(1))) *gptr_d;
 typedef int __attribute__((address_space(3))) *lptr_i;
@@ -112,53 +113,85 @@ template <class T> DEV T *uni_ptr(T *p)
 #define FS_AD 2           // register-ring depth: Sigma operands are fetched FS_AD - 1 k-blocks ahead
 #endif
 
-// One 16-row k-block (4 k-steps) for two row tiles against the FS_NU 16-feature sub-tiles of the
-// staged Gram block.  Everything that comes from beyond L2 is fetched ahead into register rings
-// indexed at compile time (CUR = h mod FS_AD): block h consumes Sigma slot CUR and issues the Sigma
-// loads of block h + FS_AD - 1; Gram rows of block h + 2 are requested into their ring and those of
-// block h + 1 (requested during block h - 1) are written to LDS.  No register copies and no branch
-// between a load and its use: the compiler keeps counted s_waitcnt vmcnt(N) and the loads stay in
-// flight across blocks of matrix ops and barriers.  (The function must not spill: a scratch reload
-// pending at loop entry turns into a static s_waitcnt vmcnt(0) inside the loop.)
-//   w0 / w1: 2.0 while THIS k-block is strictly below the tile's diagonal block, 1.0 on it
-//   (Sigma is symmetric: row tile J only visits k-blocks P <= J and counts P < J twice; doubling an
-//   operand is exact).
-#define FS_RPW ((16 + FS_NWAVES - 1) / FS_NWAVES)
-// The tile activity (act0 / act1, wave-uniform) only guards MFMA groups -- never a load -- so the
-// load/wait bookkeeping is identical on every path; an inactive tile's operand loads are pointed at
-// one fixed, cache-resident address.
-template <int CUR>
-DEV void fs_kblock(gptr_cd Sig, gptr_cd G, lptr_i lused, lptr_d cur, lptr_d nxt, int ld, int row_max,
-                   int roff0, int roff1, int h, bool act0, bool act1, bool nxt0, bool nxt1, double w0, double w1,
-                   int M, int K, const int (&istage)[FS_NH], int wave, int lane, double (&a)[FS_AD][4][2],
-                   double (&sv)[FS_AD][FS_RPW][FS_NH], d4 (&acc)[2][FS_NU])
+// The full-stat pass is ONE software pipeline over all (feature tile, pass, k-block) steps of a call:
+// a cursor names the step; the Sigma operands of the next step and the Gram rows of the step after
+// that are requested while the current step's matrix ops run, across pass and tile boundaries, so
+// memory latency is exposed once per call and not once per tile.
+struct FsCur { int i0, pass, h, last; };          // feature tile origin, row-tile pass, k-block, last k-block of the pass
+DEV void fs_advance(FsCur &c, int n_pass, int nJ, int tiles_per_pass)
 {
-    constexpr int NX1 = (CUR + 1) % FS_AD, NX2 = (CUR + 2) % FS_AD, NXA = (CUR + FS_AD - 1) % FS_AD;
+    c.h++;
+    if (c.h > c.last) {
+        c.h = 0;
+        c.pass++;
+        if (c.pass == n_pass) { c.pass = 0; c.i0 += FS_FT; }
+        const int e = c.pass * tiles_per_pass + tiles_per_pass;
+        c.last = (e < nJ ? e : nJ) - 1;
+    }
+}
+
+// One step = one 16-row k-block (4 k-steps) of one pass of one feature tile, for this wave's two row
+// tiles against the FS_NU 16-feature sub-tiles of the Gram block staged in LDS (`cur`).
+//   * issues the Gram-row loads of step g+2 (cursor c2) and the Sigma-operand loads of step g+1 (c1)
+//     into register rings indexed at compile time (CUR = g & 1); consumes the Sigma operands of c0;
+//   * a tile whose diagonal block this is (h == J) is finished: its share of sum_j T[j][i] b_j[i] and
+//     sum_j b_j[i] mu_j is folded right here from the staged rows -- the k-block on the diagonal IS the
+//     tile's own rows -- and added to this wave's slice of qbuf; its accumulators are cleared;
+//   * writes the Gram rows of step g+1 (requested during step g-1) to the other LDS buffer.
+// Activity flags are wave-uniform and guard matrix ops / the fold only -- never a load -- so the
+// load/wait bookkeeping is identical on every path; loads of inactive tiles go to one fixed address.
+// (The function must not spill and nothing may be pending at loop entry: either becomes a static
+// s_waitcnt vmcnt(0) inside the loop.)
+//   w: 2.0 while the k-block is strictly below the tile's diagonal block, 1.0 on it (Sigma is
+//   symmetric: row tile J only visits k-blocks P <= J and counts P < J twice; doubling is exact).
+#define FS_RPW ((16 + FS_NWAVES - 1) / FS_NWAVES)
+template <int CUR>
+DEV void fs_step(gptr_cc Sig, gptr_cc G, lptr_i lused, lptr_d lmu, lptr_d cur, lptr_d nxt, lptr_d qbuf, int ld,
+                 const FsCur &c0, const FsCur &c1, const FsCur &c2, int tiles_per_pass, int nJ, int M, int K,
+                 int wave, int lane, double (&a)[2][4][2], double (&sv)[2][FS_RPW][FS_NH], d4 (&acc)[2][FS_NU])
+{
+    constexpr int NX = CUR ^ 1;
     const int l15 = lane & 15, l4 = lane >> 4;
+    // Every address is "uniform 64-bit base (SGPRs) + 32-bit lane byte offset": plain 32-bit integer
+    // work.  FP64 / 64-bit vector ops are not free next to v_mfma_f64 -- they take turns on the same
+    // pipe (tools/ubench/mfma_f64_mix.hip) -- so the step keeps them to the operand doubling.
+    // Gram rows of step g+2 -> ring slot CUR (its previous content went to LDS during step g-1)
 #pragma unroll
     for (int r = 0; r < FS_RPW; r++) {
-        const int pp = (h + 2) * 16 + wave + r * FS_NWAVES;
-        const gptr_cd grow = G + (size_t)lused[pp < M ? pp : M - 1] * K;
+        const int pp = c2.h * 16 + wave + r * FS_NWAVES;
+        const int rid = uni(lused[pp < M ? pp : M - 1]);
+        const gptr_cc grow = G + (size_t)rid * (size_t)K * 8;
 #pragma unroll
-        for (int e = 0; e < FS_NH; e++) sv[NX2][r][e] = grow[istage[e]];
+        for (int e = 0; e < FS_NH; e++) {
+            const int i = c2.i0 + e * 64 + lane;
+            sv[CUR][r][e] = *(gptr_cd)(grow + (unsigned)((i < K ? i : K - 1) * 8));
+        }
     }
+    // this wave's row tiles in the current and in the next step's pass
+    const int jt0 = c0.pass * tiles_per_pass + wave, jt1 = c0.pass * tiles_per_pass + 2 * FS_NWAVES - 1 - wave;
+    const int J0 = jt0 < nJ ? jt0 : -1, J1 = jt1 < nJ ? jt1 : -1;
+    const int nt0 = c1.pass * tiles_per_pass + wave, nt1 = c1.pass * tiles_per_pass + 2 * FS_NWAVES - 1 - wave;
+    const bool nxt0 = nt0 < nJ && c1.h <= nt0, nxt1 = nt1 < nJ && c1.h <= nt1;
+    const bool act0 = c0.h <= J0, act1 = c0.h <= J1;
+    const double w0 = c0.h < J0 ? 2.0 : 1.0, w1 = c0.h < J1 ? 2.0 : 1.0;
+    // Sigma operand of k-step s: element [k = 16 h + 4 s + l4][row = 16 J + l15]; ld is a multiple of 16,
+    // so whole blocks stay inside the allocation.  A tile that is retired by then reads one fixed line.
+    const unsigned lane_off = (unsigned)((l4 * ld + l15) * 8);
+    const unsigned o0 = nxt0 ? (unsigned)((c1.h * 16 * ld + nt0 * 16) * 8) + lane_off : 0u;
+    const unsigned o1 = nxt1 ? (unsigned)((c1.h * 16 * ld + nt1 * 16) * 8) + lane_off : 0u;
+    const unsigned sstride0 = nxt0 ? (unsigned)(4 * ld * 8) : 0u, sstride1 = nxt1 ? (unsigned)(4 * ld * 8) : 0u;
     const lptr_d brow = cur + l4 * FS_LD + l15;
-    const int r0 = nxt0 ? roff0 : 0, r1 = nxt1 ? roff1 : 0;    // tile retired by then: one fixed address
 #pragma unroll
     for (int s = 0; s < 4; s++) {
         double bv[FS_NU];
 #pragma unroll
         for (int u = 0; u < FS_NU; u++) bv[u] = brow[s * 4 * FS_LD + u * 16];
-        {
-            const int pk = (h + FS_AD - 1) * 16 + s * 4 + l4;
-            const int pc = pk < row_max ? pk : row_max;
-            a[NXA][s][0] = Sig[(unsigned)((nxt0 ? pc : 0) * ld + r0)];
-            a[NXA][s][1] = Sig[(unsigned)((nxt1 ? pc : 0) * ld + r1)];
-        }
+        a[NX][s][0] = *(gptr_cd)(Sig + (o0 + s * sstride0));
+        a[NX][s][1] = *(gptr_cd)(Sig + (o1 + s * sstride1));
         double av0 = a[CUR][s][0] * w0;                        // doubled at use, not at load
         double av1 = a[CUR][s][1] * w1;
-        // consume both operands on every path: if the multiply sinks into the guarded MFMA group an
-        // inactive tile leaves its load pending on the back edge (static s_waitcnt vmcnt(0) next iteration)
+        // consume both operands on every path: if the multiply sinks into the guarded group an inactive
+        // tile leaves its load pending on the back edge (static s_waitcnt vmcnt(0) next iteration)
         asm volatile("" : "+v"(av0), "+v"(av1));
         if (act0) {
 #pragma unroll
@@ -169,12 +202,50 @@ DEV void fs_kblock(gptr_cd Sig, gptr_cd G, lptr_i lused, lptr_d cur, lptr_d nxt,
             for (int u = 0; u < FS_NU; u++) acc[1][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av1, bv[u], acc[1][u], 0, 0, 0);
         }
     }
+    // finished tiles: D register r of lane l is T[row = (l >> 4) + 4 r][col = l & 15]
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        if (c0.h == (t ? J1 : J0)) {
+            double q[FS_NU], m[FS_NU];
+#pragma unroll
+            for (int u = 0; u < FS_NU; u++) { q[u] = 0; m[u] = 0; }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const double muj = lmu[c0.h * 16 + l4 + 4 * r];
+#pragma unroll
+                for (int u = 0; u < FS_NU; u++) {
+                    const double bj = cur[(l4 + 4 * r) * FS_LD + u * 16 + l15];
+                    q[u] += acc[t][u][r] * bj;
+                    m[u] += bj * muj;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < FS_NU; u++) {
+                q[u] += __shfl_xor(q[u], 16, 64); q[u] += __shfl_xor(q[u], 32, 64);
+                m[u] += __shfl_xor(m[u], 16, 64); m[u] += __shfl_xor(m[u], 32, 64);
+                acc[t][u] = d4{0, 0, 0, 0};
+            }
+            if (lane < 16) {                                   // each wave owns its slice of qbuf: no race
+#pragma unroll
+                for (int u = 0; u < FS_NU; u++) {
+                    qbuf[wave * FS_FT + u * 16 + l15] += q[u];
+                    qbuf[(FS_NWAVES + wave) * FS_FT + u * 16 + l15] += m[u];
+                }
+            }
+        }
+    }
+    // Gram rows of step g+1 -> the other LDS buffer (rows past the active set are staged as zeros)
 #pragma unroll
     for (int r = 0; r < FS_RPW; r++) {
-        const int row = wave + r * FS_NWAVES, pp = (h + 1) * 16 + row;
+        const int row = wave + r * FS_NWAVES, pp = c1.h * 16 + row;
         if (row < 16) {
+            if (pp < M) {
 #pragma unroll
-            for (int e = 0; e < FS_NH; e++) nxt[row * FS_LD + e * 64 + lane] = pp < M ? sv[NX1][r][e] : 0.0;
+                for (int e = 0; e < FS_NH; e++) nxt[row * FS_LD + e * 64 + lane] = sv[NX][r][e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < FS_NH; e++) nxt[row * FS_LD + e * 64 + lane] = 0.0;
+            }
         }
     }
 }
@@ -202,167 +273,118 @@ DEVNI void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W,
         W.Qin[i] = beta * (W.bt[i] - bm);
     }
 #else
-    // T = Sigma * Bt on the FP64 matrix cores (v_mfma_f64_16x16x4_f64), 16 x 16 tiles of T:
-    // rows j of Sigma x features i.  An FS_FT-feature Gram tile is staged through LDS in 16-row
-    // k-blocks; every wave owns up to two 16-row tiles of Sigma per pass (w and 2 NW - 1 - w: with the
-    // triangular, symmetric schedule both halves cost the same) and multiplies them against all
-    // FS_NU 16-feature sub-tiles, so each Sigma operand fetched from memory feeds FS_NU matrix ops.
-    // quad_i = sum_j T[j][i] * Bt[j][i] is folded in the epilogue (per pass, into LDS) with two
-    // xor-shuffles over the four row groups of the accumulator layout.
+    // T = Sigma * Bt on the FP64 matrix cores (v_mfma_f64_16x16x4_f64), 16 x 16 tiles of T: rows j of
+    // Sigma x features i.  An FS_FT-feature Gram tile is staged through LDS one 16-row k-block at a
+    // time; every wave owns up to two 16-row tiles of Sigma per pass (w and 2 NW - 1 - w: with the
+    // triangular, symmetric schedule both halves cost the same) and multiplies them against all FS_NU
+    // 16-feature sub-tiles, so each Sigma operand fetched from memory feeds FS_NU matrix ops.
     //   A: lane l holds A[row = l & 15][k = l >> 4];  B: lane l holds B[k = l >> 4][col = l & 15]
-    //   D: register r of lane l is D[row = (l >> 4) + 4 r][col = l & 15]      (f64 layout)
     // No masking in the k-loop: Gram rows >= M are staged as zeros, so Sigma entries beyond the
-    // active block (finite: the workspace is zero-initialised) contribute exactly 0; rows >= M of T
-    // are never read back.
+    // active block (finite: the workspace is zero-initialised) contribute exactly 0.
     // B lives in memory (reference argument of a non-inlined function): take register copies once, or
-    // every use in the k-loop becomes a flat load followed by s_waitcnt vmcnt(0), draining the prefetches
+    // every use in the loop becomes a flat load followed by s_waitcnt vmcnt(0), draining the prefetches.
     const int lane = B.lane, wave = uni(B.wave), tid = B.tid, nthr = uni(B.nthr);
     const gptr_cd Sig = as_global(uni_ptr(W.Sig));
     const gptr_cd G = as_global(uni_ptr(F.G));
+    // results leave through global-address-space pointers taken once: a flat access inside the loop
+    // (pointer fields of W re-read from memory, flat stores) makes every later wait a full vmcnt(0)
+    const gptr_d gSin = as_global_rw(uni_ptr(W.Sin)), gQin = as_global_rw(uni_ptr(W.Qin));
+    const gptr_cd gbt = as_global(uni_ptr(W.bt));
     double *pool = uni_ptr(B.pool);
-    const lptr_d lt = as_lds(pool);
-    const lptr_i lused = as_lds((int *)(pool + 2 * FS_PC * FS_LD));   // active-set row ids, M <= 2048
-    const lptr_d qred = as_lds(pool + 2 * FS_PC * FS_LD + 1024);      // [2][NW][FS_FT] per-wave partial sums
+    const lptr_d lt = as_lds(pool);                                              // 2 x 16 x FS_LD staged Gram rows
+    const lptr_i lused = as_lds((int *)(pool + 2 * FS_PC * FS_LD));              // active-set row ids, M <= 2048
+    const lptr_d lmu = as_lds(pool + 2 * FS_PC * FS_LD + 1024);                  // mu, zero-padded to a k-block
+    const lptr_d qred = as_lds(pool + 2 * FS_PC * FS_LD + 1024 + 2064);          // [2 tiles][2][NW][FS_FT] partial sums
     K = uni(K); M = uni(M);
     const int ld = uni(W.ld);
-    __syncthreads();
-    for (int p = tid; p < M; p += nthr) lused[p] = W.rowid[p];
-    __syncthreads();
-    const int NW = uni(B.nwave);
-    const int l15 = lane & 15, l4 = lane >> 4;
     const int nJ = (M + 15) >> 4;
-    const int tiles_per_pass = NW * FS_JTW;
+    const int tiles_per_pass = FS_NWAVES * FS_JTW;
     const int n_pass = (nJ + tiles_per_pass - 1) / tiles_per_pass;
     const int row_max = uni(W.cap) - 1;
-    for (int i0 = 0; i0 < K; i0 += FS_FT) {
-        int istage[FS_NH];
+    const int n_ft = (K + FS_FT - 1) / FS_FT;
+    int steps_per_tile = 0;
+    for (int p = 0; p < n_pass; p++) { const int e = p * tiles_per_pass + tiles_per_pass; steps_per_tile += (e < nJ ? e : nJ); }
+    const int total = n_ft * steps_per_tile;
+    __syncthreads();
+    for (int p = tid; p < nJ * 16; p += nthr) { lused[p < M ? p : 0] = W.rowid[p < M ? p : 0]; lmu[p] = p < M ? W.mu[p] : 0.0; }
+    for (int e = tid; e < 2 * 2 * FS_NWAVES * FS_FT; e += nthr) qred[e] = 0.0;
+    __syncthreads();
+    FsCur c0, c1, c2;
+    c0.i0 = 0; c0.pass = 0; c0.h = 0; c0.last = (tiles_per_pass < nJ ? tiles_per_pass : nJ) - 1;
+    c1 = c0; fs_advance(c1, n_pass, nJ, tiles_per_pass);
+    c2 = c1; fs_advance(c2, n_pass, nJ, tiles_per_pass);
+    d4 acc[FS_JTW][FS_NU];
 #pragma unroll
-        for (int e = 0; e < FS_NH; e++) istage[e] = (i0 + e * 64 + lane) < K ? (i0 + e * 64 + lane) : K - 1;
-        for (int e = tid; e < 2 * NW * FS_FT; e += nthr) qred[e] = 0.0;     // visible after the barriers below
-        for (int pass = 0; pass < n_pass; pass++) {
-            const int jbase = pass * tiles_per_pass;
-            int jts[FS_JTW], roff[FS_JTW];
-            jts[0] = jbase + wave;                          // w and 2 NW - 1 - w: with the triangular
-            jts[1] = jbase + 2 * NW - 1 - wave;             // schedule both halves cost the same
+    for (int t = 0; t < FS_JTW; t++)
 #pragma unroll
-            for (int t = 0; t < FS_JTW; t++) {
-                const int row = jts[t] * 16 + l15;
-                roff[t] = row < row_max ? row : row_max;
-            }
-            // wave-uniform schedule: tile 0 is active for k-blocks 0..J0, tile 1 for 0..J1 (J0 < J1)
-            const int J0 = __builtin_amdgcn_readfirstlane(jts[0] < nJ ? jts[0] : -1);
-            const int J1 = __builtin_amdgcn_readfirstlane(jts[1] < nJ ? jts[1] : -1);
-            const int last_tile = (jbase + tiles_per_pass < nJ ? jbase + tiles_per_pass : nJ) - 1;
-            d4 acc[FS_JTW][FS_NU];
+        for (int u = 0; u < FS_NU; u++) acc[t][u] = d4{0, 0, 0, 0};
+    double a[2][4][2], sv[2][FS_RPW][FS_NH];
+    {   // pipeline fill: Sigma operands of step 0 (slot 0), Gram rows of step 0 (LDS buffer 0) and of step 1 (slot 1)
+        const int l15 = lane & 15, l4 = lane >> 4;
+        const int jt0 = wave, jt1 = 2 * FS_NWAVES - 1 - wave;
+        int r0 = jt0 * 16 + l15, r1 = jt1 * 16 + l15;
+        r0 = r0 < row_max ? r0 : row_max; r1 = r1 < row_max ? r1 : row_max;
 #pragma unroll
-            for (int t = 0; t < FS_JTW; t++)
+        for (int sidx = 0; sidx < 4; sidx++) {
+            const int pk = sidx * 4 + l4;
+            const unsigned b0 = (unsigned)((pk < row_max ? pk : row_max) * ld);
+            a[0][sidx][0] = Sig[b0 + r0]; a[0][sidx][1] = Sig[b0 + r1];
+        }
 #pragma unroll
-                for (int u = 0; u < FS_NU; u++) acc[t][u] = d4{0, 0, 0, 0};
-            double a[FS_AD][4][2], sv[FS_AD][FS_RPW][FS_NH];
-            {   // Sigma operands of k-blocks 0 .. FS_AD-2 (slots 0 ..), Gram rows of k-block 1 (slot 1)
+        for (int r = 0; r < FS_RPW; r++) {
+            const int row = wave + r * FS_NWAVES;
+            const int p0 = row, p1 = c1.h * 16 + row;
+            const gptr_cd g0 = G + (size_t)lused[p0 < M ? p0 : M - 1] * K;
+            const gptr_cd g1 = G + (size_t)lused[p1 < M ? p1 : M - 1] * K;
 #pragma unroll
-                for (int blk = 0; blk < FS_AD - 1; blk++)
-#pragma unroll
-                    for (int sidx = 0; sidx < 4; sidx++) {
-                        const int pk = blk * 16 + sidx * 4 + l4;
-                        const unsigned b0 = (unsigned)((pk < row_max ? pk : row_max) * ld);
-                        a[blk][sidx][0] = Sig[b0 + roff[0]]; a[blk][sidx][1] = Sig[b0 + roff[1]];
-                    }
-#pragma unroll
-                for (int r = 0; r < FS_RPW; r++) {
-                    const int pp = 16 + wave + r * FS_NWAVES;
-                    const gptr_cd grow = G + (size_t)lused[pp < M ? pp : M - 1] * K;
-#pragma unroll
-                    for (int e = 0; e < FS_NH; e++) sv[1][r][e] = grow[istage[e]];
-                }
-            }
-            __syncthreads();
-            for (int row = wave; row < 16; row += NW) {
-                const gptr_cd grow = G + (size_t)lused[row < M ? row : M - 1] * K;
-#pragma unroll
-                for (int e = 0; e < FS_NH; e++) lt[row * FS_LD + e * 64 + lane] = (row < M) ? grow[istage[e]] : 0.0;
-            }
-            // nothing may be pending at loop entry: a load still in flight here makes the compiler put
-            // a static s_waitcnt vmcnt(0) inside the loop (it merges this state into every iteration)
-            __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0), visible to the compiler's wait tracking
-            __syncthreads();
-#define FS_STEP(CURSLOT, hh)                                                                                         \
-            {                                                                                                        \
-                const int h_ = (hh);                                                                                 \
-                const lptr_d cur = lt + (h_ & 1) * (FS_PC * FS_LD);                                                  \
-                const lptr_d nxt = lt + ((h_ + 1) & 1) * (FS_PC * FS_LD);                                            \
-                const double w0 = (h_ < J0) ? 2.0 : 1.0, w1 = (h_ < J1) ? 2.0 : 1.0;                                 \
-                fs_kblock<CURSLOT>(Sig, G, lused, cur, nxt, ld, row_max, roff[0], roff[1], h_, h_ <= J0, h_ <= J1,   \
-                                   h_ + FS_AD - 1 <= J0, h_ + FS_AD - 1 <= J1, w0, w1, M, K, istage, wave, lane,    \
-                                   a, sv, acc);                                                                      \
-                __syncthreads();                                                                                     \
-            }
-            // whole groups of FS_AD steps without any skip path inside the loop (a skipped step would leave
-            // its predecessor's prefetch pending on the back edge: static s_waitcnt vmcnt(0)); then the tail
-            int h = 0;
-#if FS_AD == 2
-            for (; h + 1 <= last_tile; h += 2) {
-                FS_STEP(0, h)
-                FS_STEP(1, h + 1)
-            }
-            if (h <= last_tile) FS_STEP(0, h)
-#else
-            for (; h + 2 <= last_tile; h += 3) {
-                FS_STEP(0, h)
-                FS_STEP(1, h + 1)
-                FS_STEP(2, h + 2)
-            }
-            if (h <= last_tile) FS_STEP(0, h)
-            if (h + 1 <= last_tile) FS_STEP(1, h + 1)
-#endif
-#undef FS_STEP
-            // epilogue of the pass: this wave's share of sum_j T[j][i] b_j[i] and sum_j b_j[i] mu_j
-            double q_acc[FS_NU], m_acc[FS_NU];
-#pragma unroll
-            for (int u = 0; u < FS_NU; u++) { q_acc[u] = 0; m_acc[u] = 0; }
-#pragma unroll
-            for (int t = 0; t < FS_JTW; t++) {
-                if (jts[t] < nJ) {
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const int j = jts[t] * 16 + l4 + 4 * r;
-                        if (j < M) {
-                            const gptr_cd grow = G + (size_t)lused[j] * K;
-                            const double muj = W.mu[j];
-#pragma unroll
-                            for (int u = 0; u < FS_NU; u++) {
-                                const int ic = i0 + u * 16 + l15;
-                                const double bj = grow[ic < K ? ic : K - 1];
-                                q_acc[u] += acc[t][u][r] * bj;
-                                m_acc[u] += bj * muj;
-                            }
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < FS_NU; u++) {
-                q_acc[u] += __shfl_xor(q_acc[u], 16, 64); q_acc[u] += __shfl_xor(q_acc[u], 32, 64);
-                m_acc[u] += __shfl_xor(m_acc[u], 16, 64); m_acc[u] += __shfl_xor(m_acc[u], 32, 64);
-            }
-            if (lane < 16) {                                 // each wave owns its slice of qred: no race
-#pragma unroll
-                for (int u = 0; u < FS_NU; u++) {
-                    qred[wave * FS_FT + u * 16 + l15] += q_acc[u];
-                    qred[(NW + wave) * FS_FT + u * 16 + l15] += m_acc[u];
-                }
+            for (int e = 0; e < FS_NH; e++) {
+                const int i_0 = e * 64 + lane, i_1 = c1.i0 + e * 64 + lane;
+                const double v0 = g0[i_0 < K ? i_0 : K - 1];
+                sv[1][r][e] = g1[i_1 < K ? i_1 : K - 1];
+                if (row < 16) lt[row * FS_LD + e * 64 + lane] = p0 < M ? v0 : 0.0;
             }
         }
-        __syncthreads();
-        if (tid < FS_FT && i0 + tid < K) {
-            const int i = i0 + tid;
-            double q = 0, m = 0;
-            for (int w = 0; w < NW; w++) { q += qred[w * FS_FT + tid]; m += qred[(NW + w) * FS_FT + tid]; }
-            W.Sin[i] = beta - beta * q * beta;
-            W.Qin[i] = beta * (W.bt[i] - m);
-        }
-        __syncthreads();
     }
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): nothing pending at loop entry (see fs_step); the compiler tracks this form
+    __syncthreads();
+    // After the barrier that ends the last step of a feature tile, the first FS_FT threads sum the
+    // per-wave partials of that tile (qred is double-buffered by tile parity) while the other waves
+    // already run the next tile.
+#define FS_FINISH_TILE(cc)                                                                                           \
+        if ((cc).h == (cc).last && (cc).pass == n_pass - 1) {                                                        \
+            const lptr_d qb = qred + (((cc).i0 / FS_FT) & 1) * (2 * FS_NWAVES * FS_FT);                              \
+            if (tid < FS_FT) {                                                                                       \
+                const int i = (cc).i0 + tid;                                                                         \
+                double q = 0, m = 0;                                                                                 \
+                for (int w = 0; w < FS_NWAVES; w++) {                                                                \
+                    q += qb[w * FS_FT + tid]; m += qb[(FS_NWAVES + w) * FS_FT + tid];                                \
+                    qb[w * FS_FT + tid] = 0.0; qb[(FS_NWAVES + w) * FS_FT + tid] = 0.0;                              \
+                }                                                                                                    \
+                if (i < K) { gSin[i] = beta - beta * q * beta; gQin[i] = beta * (gbt[i] - m); }                      \
+            }                                                                                                        \
+        }
+#define FS_STEP(CURSLOT, gg)                                                                                         \
+        {                                                                                                            \
+            const lptr_d cur = lt + ((gg) & 1) * (FS_PC * FS_LD);                                                    \
+            const lptr_d nxt = lt + (((gg) + 1) & 1) * (FS_PC * FS_LD);                                              \
+            const lptr_d qb = qred + ((c0.i0 / FS_FT) & 1) * (2 * FS_NWAVES * FS_FT);                                \
+            fs_step<CURSLOT>((gptr_cc)Sig, (gptr_cc)G, lused, lmu, cur, nxt, qb, ld, c0, c1, c2, tiles_per_pass, nJ, \
+                             M, K,                                                                                   \
+                             wave, lane, a, sv, acc);                                                                \
+            __syncthreads();                                                                                         \
+            FS_FINISH_TILE(c0)                                                                                       \
+            c0 = c1; c1 = c2; fs_advance(c2, n_pass, nJ, tiles_per_pass);                                            \
+        }
+    // whole pairs of steps without any skip path inside the loop (a skipped step would leave its
+    // predecessor's prefetch pending on the back edge: static s_waitcnt vmcnt(0)); then the odd tail
+    int g = 0;
+    for (; g + 1 < total; g += 2) {
+        FS_STEP(0, g)
+        FS_STEP(1, g + 1)
+    }
+    if (g < total) FS_STEP(0, g)
+#undef FS_STEP
+#undef FS_FINISH_TILE
 #endif
     blk_sync(B);
 }

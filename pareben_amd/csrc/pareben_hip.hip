@@ -200,10 +200,10 @@ __host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a -
 static WsLayout ws_layout(int K, int cap)
 {
     WsLayout L;
-    L.cap = cap; L.ld = cap;
+    L.cap = cap; L.ld = (cap + 15) / 16 * 16;      // whole 16-row blocks: the matrix-core passes index rows without clamps
     size_t o = 0;
     L.offK = o;   o += align_up((size_t)K * (7 * sizeof(double) + 2 * sizeof(int) + 1), 256);
-    L.offSig = o; o += align_up((size_t)2 * cap * cap * sizeof(double), 256);
+    L.offSig = o; o += align_up((size_t)2 * L.ld * L.ld * sizeof(double), 256);
     L.offM = o;   o += align_up((size_t)(cap + 2) * (7 * sizeof(double) + 3 * sizeof(int)), 256);
     L.bytes = align_up(o, 4096);
     return L;
@@ -219,7 +219,8 @@ __device__ inline GmWork ws_carve(char *base, int K, int cap, size_t offK, size_
     W.upos = ip; ip += K; W.todo = ip; ip += K;
     W.act = (signed char *)ip;
     d = (double *)(base + offSig);
-    W.Sig = d; d += (size_t)cap * cap; W.H = d;
+    const int ldp = (cap + 15) / 16 * 16;
+    W.Sig = d; d += (size_t)ldp * ldp; W.H = d;
     d = (double *)(base + offM);
     const int c1 = cap + 1;
     W.A = d; d += c1; W.mu = d; d += c1; W.gam = d; d += c1;
@@ -229,7 +230,7 @@ __device__ inline GmWork ws_carve(char *base, int K, int cap, size_t offK, size_
     W.pfree = W.rowid + c1;
     W.priv_base = 0; W.priv_rows = 0;
     W.e = nullptr;
-    W.cap = cap; W.ld = cap;
+    W.cap = cap; W.ld = ldp;
     return W;
 }
 
