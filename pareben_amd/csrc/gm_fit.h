@@ -521,8 +521,27 @@ DEVNI int gm_collect(const Blk &B, const GmWork &W, int K, double cutoff)
     return base;
 }
 
+// S_in / Q_in update of feature i from a = sum_j G[used[j], i] * vec[j].
+// mode 0: re-estimate (:577-587), 1: add (:1699-1711), 2: delete (:1800-1808).
+DEV void gm_sq_apply(const GmWork &W, int mode, double beta, double c1, double c2, const double *newrow, int i, double a)
+{
+    if (mode == 0) {                             // c1 = kappa, c2 = mu_jj
+        const double ba = beta * a;
+        W.Sin[i] = W.Sin[i] + ba * ba * c1;
+        W.Qin[i] = W.Qin[i] + beta * c2 * c1 * a;
+    } else if (mode == 1) {                      // c1 = s_ii, c2 = mu_i
+        const double mc = beta * newrow[i] - beta * a;
+        W.Sin[i] = W.Sin[i] - mc * mc * c1;
+        W.Qin[i] = W.Qin[i] - c2 * mc;
+    } else {                                     // c1 = Sigma_jj, c2 = (int) mu_jj
+        const double ba = beta * a;
+        W.Sin[i] = W.Sin[i] + ba * ba / c1;
+        W.Qin[i] = W.Qin[i] + ba * c2 / c1;
+    }
+}
+
 // a[i] = sum_j G[used[j], i] * vec[j] for all features, fused with the S_in/Q_in update that
-// consumes it.  mode 0: re-estimate (:577-587), 1: add (:1699-1711), 2: delete (:1800-1808).
+// consumes it.
 DEVNI void gm_sq_update(const Blk &B, const FoldDev &F, const GmWork &W, int K, int M, const double *vec,
                         int mode, double beta, double c1, double c2, const double *newrow)
 {
@@ -530,55 +549,65 @@ DEVNI void gm_sq_update(const Blk &B, const FoldDev &F, const GmWork &W, int K, 
     PAR(i, K) {
         double a = 0;
         for (int j = 0; j < M; j++) a += F.G[(size_t)W.rowid[j] * K + i] * vec[j];
+        gm_sq_apply(W, mode, beta, c1, c2, newrow, i, a);
+    }
 #else
-    // K x M mat-vec over Gram rows: `used`/`vec` staged in LDS, SQ_Q features per thread so that
-    // SQ_Q independent coalesced row loads are in flight per active feature.
-    constexpr int SQ_Q = 10;
-    const gptr_cd G = as_global(F.G);
+    // K x M mat-vec over Gram rows: row ids / `vec` staged in LDS; every thread owns SQ_Q PAIRS of
+    // adjacent features and fetches each pair with one 16-byte load (row base in SGPRs + 32-bit lane
+    // offset), so SQ_Q independent coalesced 1 KB row segments per wave are in flight per active row.
+    constexpr int SQ_Q = 5;
+    typedef double d2 __attribute__((ext_vector_type(2), aligned(8)));   // rows of an odd-K matrix start 8 bytes off
+    typedef const d2 __attribute__((address_space(1))) *gptr_cd2;
+    const gptr_cc G = (gptr_cc)as_global(uni_ptr(F.G));
     const lptr_d lvec = as_lds(B.pool);
     const lptr_i lused = as_lds((int *)(B.pool + ((M + 1) & ~1)));
+    const int tid = B.tid, nthr = uni(B.nthr);
+    K = uni(K); M = uni(M);
     blk_sync(B);
-    PAR(j, M) { lvec[j] = vec[j]; lused[j] = W.rowid[j]; }
+    for (int j = tid; j < M; j += nthr) { lvec[j] = vec[j]; lused[j] = W.rowid[j]; }
     blk_sync(B);
-    for (int ib = 0; ib < K; ib += SQ_Q * B.nthr) {
-        double accq[SQ_Q];
-        int idx[SQ_Q];
+    const int Kp = K & ~1;                                    // pairs cover [0, Kp); an odd last feature is handled below
+    for (int ib = 0; ib < Kp; ib += 2 * SQ_Q * nthr) {
+        d2 accq[SQ_Q];
+        unsigned off[SQ_Q];
 #pragma unroll
         for (int q = 0; q < SQ_Q; q++) {
-            accq[q] = 0;
-            const int i = ib + q * B.nthr + B.tid;
-            idx[q] = i < K ? i : K - 1;
+            accq[q] = d2{0, 0};
+            const int i = ib + 2 * (q * nthr + tid);
+            off[q] = (unsigned)((i < Kp ? i : Kp - 2) * 8);
         }
-#pragma unroll 2
-        for (int j = 0; j < M; j++) {
-            const gptr_cd row = G + (size_t)lused[j] * K;
-            const double vj = lvec[j];
+        int j = 0;
+        for (; j + 1 < M; j += 2) {                            // two rows per trip: 2 SQ_Q loads in flight per thread
+            const gptr_cc row0 = G + (size_t)uni(lused[j]) * (size_t)K * 8;
+            const gptr_cc row1 = G + (size_t)uni(lused[j + 1]) * (size_t)K * 8;
+            const double v0 = lvec[j], v1 = lvec[j + 1];
+            d2 g0[SQ_Q], g1[SQ_Q];
 #pragma unroll
-            for (int q = 0; q < SQ_Q; q++) accq[q] += row[idx[q]] * vj;
+            for (int q = 0; q < SQ_Q; q++) { g0[q] = *(gptr_cd2)(row0 + off[q]); g1[q] = *(gptr_cd2)(row1 + off[q]); }
+#pragma unroll
+            for (int q = 0; q < SQ_Q; q++) { accq[q] += g0[q] * v0; accq[q] += g1[q] * v1; }
+        }
+        if (j < M) {
+            const gptr_cc row0 = G + (size_t)uni(lused[j]) * (size_t)K * 8;
+            const double v0 = lvec[j];
+#pragma unroll
+            for (int q = 0; q < SQ_Q; q++) accq[q] += *(gptr_cd2)(row0 + off[q]) * v0;
         }
 #pragma unroll
         for (int q = 0; q < SQ_Q; q++) {
-        const int i = ib + q * B.nthr + B.tid;
-        if (i >= K) continue;
-        const double a = accq[q];
-#endif
-        if (mode == 0) {                         // c1 = kappa, c2 = mu_jj
-            const double ba = beta * a;
-            W.Sin[i] = W.Sin[i] + ba * ba * c1;
-            W.Qin[i] = W.Qin[i] + beta * c2 * c1 * a;
-        } else if (mode == 1) {                  // c1 = s_ii, c2 = mu_i
-            const double mc = beta * newrow[i] - beta * a;
-            W.Sin[i] = W.Sin[i] - mc * mc * c1;
-            W.Qin[i] = W.Qin[i] - c2 * mc;
-        } else {                                 // c1 = Sigma_jj, c2 = (int) mu_jj
-            const double ba = beta * a;
-            W.Sin[i] = W.Sin[i] + ba * ba / c1;
-            W.Qin[i] = W.Qin[i] + ba * c2 / c1;
+            const int i = ib + 2 * (q * nthr + tid);
+            if (i < Kp) {
+                gm_sq_apply(W, mode, beta, c1, c2, newrow, i, accq[q][0]);
+                gm_sq_apply(W, mode, beta, c1, c2, newrow, i + 1, accq[q][1]);
+            }
         }
-#ifndef PAREBEN_HOST_EMUL
-        }
-#endif
     }
+    if ((K & 1) && tid == 0) {                                // the odd last feature
+        double a = 0;
+        for (int j = 0; j < M; j++) a += *(gptr_cd)(G + ((size_t)lused[j] * (size_t)K + (K - 1)) * 8) * lvec[j];
+        gm_sq_apply(W, mode, beta, c1, c2, newrow, K - 1, a);
+    }
+#endif
     blk_sync(B);
 }
 
