@@ -98,64 +98,63 @@ template <class T> DEV T *uni_ptr(T *p)
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return (T *)(((unsigned long long)hi << 32) | lo);
 }
-#define FS_JTW 2          // row tiles per wave and pass
-#define FS_PC 16          // Gram rows staged per chunk (= one k-block)
-#ifndef FS_FT
-#define FS_FT 128         // features per tile: Sigma operands are streamed once per FS_FT features
-#endif
-#define FS_NU (FS_FT / 16)   // 16-feature sub-tiles per tile (each Sigma operand feeds FS_NU matrix ops)
-#define FS_NH (FS_FT / 64)   // 64-lane halves of a staged Gram row
-#define FS_LD (FS_FT + 16)   // LDS row pitch in doubles (conflict-free b64 reads)
+#define FS_TPP 16          // row tiles of Sigma per pass (16 x 16 rows = 256 active features)
+#define FS_PC 16           // Gram rows staged per step (= one k-block)
 #ifndef FS_NWAVES
-#define FS_NWAVES 16      // wavefronts per fit workgroup (set by the kernel file from FIT_THREADS)
+#define FS_NWAVES 8        // wavefronts per fit workgroup (set by the kernel file from FIT_THREADS)
 #endif
-#ifndef FS_AD
-#define FS_AD 2           // register-ring depth: Sigma operands are fetched FS_AD - 1 k-blocks ahead
-#endif
+#define FS_FT (16 * FS_NWAVES)   // features per tile: every wave owns one 16-feature column block of it
+#define FS_NH (FS_FT / 64)       // 64-lane pieces of a staged Gram row
+#define FS_LD (FS_FT + 16)       // LDS row pitch of the Gram block in doubles (conflict-free b64 reads)
+#define FS_RPW (16 / FS_NWAVES)  // Gram rows each wave stages per step
+#define FS_PPW (FS_TPP / FS_NWAVES)   // Sigma panels each wave stages per step
+static_assert(16 % FS_NWAVES == 0 && FS_TPP % FS_NWAVES == 0 && FS_FT % 64 == 0, "full-stat tiling");
 
 // The full-stat pass is ONE software pipeline over all (feature tile, pass, k-block) steps of a call:
-// a cursor names the step; the Sigma operands of the next step and the Gram rows of the step after
-// that are requested while the current step's matrix ops run, across pass and tile boundaries, so
-// memory latency is exposed once per call and not once per tile.
+// a cursor names the step; what a step needs from memory is requested two steps ahead and written to
+// LDS one step ahead, across pass and tile boundaries, so memory latency is exposed once per call.
 struct FsCur { int i0, pass, h, last; };          // feature tile origin, row-tile pass, k-block, last k-block of the pass
-DEV void fs_advance(FsCur &c, int n_pass, int nJ, int tiles_per_pass)
+DEV void fs_advance(FsCur &c, int n_pass, int nJ)
 {
     c.h++;
     if (c.h > c.last) {
         c.h = 0;
         c.pass++;
         if (c.pass == n_pass) { c.pass = 0; c.i0 += FS_FT; }
-        const int e = c.pass * tiles_per_pass + tiles_per_pass;
+        const int e = c.pass * FS_TPP + FS_TPP;
         c.last = (e < nJ ? e : nJ) - 1;
     }
 }
 
-// One step = one 16-row k-block (4 k-steps) of one pass of one feature tile, for this wave's two row
-// tiles against the FS_NU 16-feature sub-tiles of the Gram block staged in LDS (`cur`).
-//   * issues the Gram-row loads of step g+2 (cursor c2) and the Sigma-operand loads of step g+1 (c1)
-//     into register rings indexed at compile time (CUR = g & 1); consumes the Sigma operands of c0;
-//   * a tile whose diagonal block this is (h == J) is finished: its share of sum_j T[j][i] b_j[i] and
-//     sum_j b_j[i] mu_j is folded right here from the staged rows -- the k-block on the diagonal IS the
-//     tile's own rows -- and added to this wave's slice of qbuf; its accumulators are cleared;
-//   * writes the Gram rows of step g+1 (requested during step g-1) to the other LDS buffer.
-// Activity flags are wave-uniform and guard matrix ops / the fold only -- never a load -- so the
-// load/wait bookkeeping is identical on every path; loads of inactive tiles go to one fixed address.
-// (The function must not spill and nothing may be pending at loop entry: either becomes a static
-// s_waitcnt vmcnt(0) inside the loop.)
-//   w: 2.0 while the k-block is strictly below the tile's diagonal block, 1.0 on it (Sigma is
-//   symmetric: row tile J only visits k-blocks P <= J and counts P < J twice; doubling is exact).
-#define FS_RPW ((16 + FS_NWAVES - 1) / FS_NWAVES)
+// One step = k-block h (16 rows of the active set) of one pass (<= 16 row tiles of Sigma) of one
+// feature tile.  T = Sigma * Bt on the FP64 matrix cores (v_mfma_f64_16x16x4_f64) in 16 x 16 tiles:
+//   A (16 rows of Sigma x 4 k):  lane l holds A[row = l & 15][k = l >> 4]
+//   B (4 k x 16 features):       lane l holds B[k = l >> 4][col = l & 15]
+//   D register r of lane l:      T[row = (l >> 4) + 4 r][col = l & 15]
+// Work split: every wave owns ONE 16-feature column block of the tile and ALL row tiles of the pass
+// (16 accumulator tiles), so at every step all waves do the same number of matrix ops -- the
+// triangular schedule below costs no balance.  Both operands come from LDS: the Gram k-block
+// (16 x FS_FT, shared) and the Sigma panels of the step ((tile J, k-block h) = 16 x 16, stored in
+// operand order so a wave reads one contiguous 512 B line per matrix op).  Each Sigma element is
+// fetched from memory once per workgroup and step and feeds all FS_NWAVES column blocks.
+// Sigma is symmetric: row tile J only visits k-blocks h <= J and counts h < J twice (the panel is
+// doubled when it is staged; doubling is exact).  Rows >= M of the Gram block are staged as zeros, so
+// Sigma entries beyond the active block (finite: the workspace is zero-initialised) contribute 0.
+// When h == J the k-block on the diagonal IS tile J's own rows: the wave folds
+// sum_j T[j][i] b_j[i] and sum_j b_j[i] mu_j for its features right there and clears the tile.
+//   * ring slot CUR (= g & 1) receives the loads of step g+2 (cursor c2); slot CUR^1 holds step g+1's
+//     data (requested during step g-1), which this step writes to the other LDS buffers.
+// Uniform branches guard matrix ops, folds and LDS writes only -- never a load -- so the load/wait
+// bookkeeping is the same on every path (counted s_waitcnt vmcnt(N); the function must not spill and
+// nothing may be pending at loop entry, or the compiler puts a static vmcnt(0) inside the loop).
 template <int CUR>
-DEV void fs_step(gptr_cc Sig, gptr_cc G, lptr_i lused, lptr_d lmu, lptr_d cur, lptr_d nxt, lptr_d qbuf, int ld,
-                 const FsCur &c0, const FsCur &c1, const FsCur &c2, int tiles_per_pass, int nJ, int M, int K,
-                 int wave, int lane, double (&a)[2][4][2], double (&sv)[2][FS_RPW][FS_NH], d4 (&acc)[2][FS_NU])
+DEV void fs_step(gptr_cc Sig, gptr_cc G, lptr_i lused, lptr_d lmu, lptr_d bcur, lptr_d bnxt, lptr_d acur, lptr_d anxt,
+                 int ld, const FsCur &c0, const FsCur &c1, const FsCur &c2, int nJ, int M, int K, int wave, int lane,
+                 double (&pa)[2][FS_PPW][4], double (&sv)[2][FS_RPW][FS_NH], d4 (&acc)[FS_TPP], double &qsum, double &msum)
 {
     constexpr int NX = CUR ^ 1;
     const int l15 = lane & 15, l4 = lane >> 4;
-    // Every address is "uniform 64-bit base (SGPRs) + 32-bit lane byte offset": plain 32-bit integer
-    // work.  FP64 / 64-bit vector ops are not free next to v_mfma_f64 -- they take turns on the same
-    // pipe (tools/ubench/mfma_f64_mix.hip) -- so the step keeps them to the operand doubling.
-    // Gram rows of step g+2 -> ring slot CUR (its previous content went to LDS during step g-1)
+    // ---- requests for step g+2: Gram rows ...
 #pragma unroll
     for (int r = 0; r < FS_RPW; r++) {
         const int pp = c2.h * 16 + wave + r * FS_NWAVES;
@@ -167,85 +166,66 @@ DEV void fs_step(gptr_cc Sig, gptr_cc G, lptr_i lused, lptr_d lmu, lptr_d cur, l
             sv[CUR][r][e] = *(gptr_cd)(grow + (unsigned)((i < K ? i : K - 1) * 8));
         }
     }
-    // this wave's row tiles in the current and in the next step's pass
-    const int jt0 = c0.pass * tiles_per_pass + wave, jt1 = c0.pass * tiles_per_pass + 2 * FS_NWAVES - 1 - wave;
-    const int J0 = jt0 < nJ ? jt0 : -1, J1 = jt1 < nJ ? jt1 : -1;
-    const int nt0 = c1.pass * tiles_per_pass + wave, nt1 = c1.pass * tiles_per_pass + 2 * FS_NWAVES - 1 - wave;
-    const bool nxt0 = nt0 < nJ && c1.h <= nt0, nxt1 = nt1 < nJ && c1.h <= nt1;
-    const bool act0 = c0.h <= J0, act1 = c0.h <= J1;
-    const double w0 = c0.h < J0 ? 2.0 : 1.0, w1 = c0.h < J1 ? 2.0 : 1.0;
-    // Sigma operand of k-step s: element [k = 16 h + 4 s + l4][row = 16 J + l15]; ld is a multiple of 16,
-    // so whole blocks stay inside the allocation.  A tile that is retired by then reads one fixed line.
-    const unsigned lane_off = (unsigned)((l4 * ld + l15) * 8);
-    const unsigned o0 = nxt0 ? (unsigned)((c1.h * 16 * ld + nt0 * 16) * 8) + lane_off : 0u;
-    const unsigned o1 = nxt1 ? (unsigned)((c1.h * 16 * ld + nt1 * 16) * 8) + lane_off : 0u;
-    const unsigned sstride0 = nxt0 ? (unsigned)(4 * ld * 8) : 0u, sstride1 = nxt1 ? (unsigned)(4 * ld * 8) : 0u;
-    const lptr_d brow = cur + l4 * FS_LD + l15;
+    // ... and this wave's share of the Sigma panels: element [k = 16 h + 4 s + l4][row = 16 J + l15]; ld is
+    // a multiple of 16, so whole blocks stay inside the allocation; an inactive panel reads one fixed line
+    {
+        const unsigned lane_off = (unsigned)((l4 * ld + l15) * 8);
 #pragma unroll
-    for (int s = 0; s < 4; s++) {
-        double bv[FS_NU];
+        for (int pi = 0; pi < FS_PPW; pi++) {
+            const int J = c2.pass * FS_TPP + wave + pi * FS_NWAVES;
+            const bool on = J < nJ && c2.h <= J;
+            const unsigned o = on ? (unsigned)((c2.h * 16 * ld + J * 16) * 8) + lane_off : 0u;
+            const unsigned st = on ? (unsigned)(4 * ld * 8) : 0u;
 #pragma unroll
-        for (int u = 0; u < FS_NU; u++) bv[u] = brow[s * 4 * FS_LD + u * 16];
-        a[NX][s][0] = *(gptr_cd)(Sig + (o0 + s * sstride0));
-        a[NX][s][1] = *(gptr_cd)(Sig + (o1 + s * sstride1));
-        double av0 = a[CUR][s][0] * w0;                        // doubled at use, not at load
-        double av1 = a[CUR][s][1] * w1;
-        // consume both operands on every path: if the multiply sinks into the guarded group an inactive
-        // tile leaves its load pending on the back edge (static s_waitcnt vmcnt(0) next iteration)
-        asm volatile("" : "+v"(av0), "+v"(av1));
-        if (act0) {
-#pragma unroll
-            for (int u = 0; u < FS_NU; u++) acc[0][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av0, bv[u], acc[0][u], 0, 0, 0);
-        }
-        if (act1) {
-#pragma unroll
-            for (int u = 0; u < FS_NU; u++) acc[1][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av1, bv[u], acc[1][u], 0, 0, 0);
+            for (int s = 0; s < 4; s++) pa[CUR][pi][s] = *(gptr_cd)(Sig + (o + s * st));
         }
     }
-    // finished tiles: D register r of lane l is T[row = (l >> 4) + 4 r][col = l & 15]
+    // ---- matrix ops of step g
+    const int jb = c0.pass * FS_TPP;
+    double bv[4];
 #pragma unroll
-    for (int t = 0; t < 2; t++) {
-        if (c0.h == (t ? J1 : J0)) {
-            double q[FS_NU], m[FS_NU];
+    for (int s = 0; s < 4; s++) bv[s] = bcur[(4 * s + l4) * FS_LD + 16 * wave + l15];
 #pragma unroll
-            for (int u = 0; u < FS_NU; u++) { q[u] = 0; m[u] = 0; }
+    for (int t = 0; t < FS_TPP; t++) {
+        const int J = jb + t;
+        if (J < nJ && c0.h <= J) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const double muj = lmu[c0.h * 16 + l4 + 4 * r];
+            for (int s = 0; s < 4; s++)
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(acur[(t * 4 + s) * 64 + lane], bv[s], acc[t], 0, 0, 0);
+            if (c0.h == J) {                                  // tile J is complete: fold and clear
 #pragma unroll
-                for (int u = 0; u < FS_NU; u++) {
-                    const double bj = cur[(l4 + 4 * r) * FS_LD + u * 16 + l15];
-                    q[u] += acc[t][u][r] * bj;
-                    m[u] += bj * muj;
+                for (int r = 0; r < 4; r++) {
+                    const double bj = bcur[(l4 + 4 * r) * FS_LD + 16 * wave + l15];
+                    qsum += acc[t][r] * bj;
+                    msum += bj * lmu[c0.h * 16 + l4 + 4 * r];
                 }
-            }
-#pragma unroll
-            for (int u = 0; u < FS_NU; u++) {
-                q[u] += __shfl_xor(q[u], 16, 64); q[u] += __shfl_xor(q[u], 32, 64);
-                m[u] += __shfl_xor(m[u], 16, 64); m[u] += __shfl_xor(m[u], 32, 64);
-                acc[t][u] = d4{0, 0, 0, 0};
-            }
-            if (lane < 16) {                                   // each wave owns its slice of qbuf: no race
-#pragma unroll
-                for (int u = 0; u < FS_NU; u++) {
-                    qbuf[wave * FS_FT + u * 16 + l15] += q[u];
-                    qbuf[(FS_NWAVES + wave) * FS_FT + u * 16 + l15] += m[u];
-                }
+                acc[t] = d4{0, 0, 0, 0};
             }
         }
     }
-    // Gram rows of step g+1 -> the other LDS buffer (rows past the active set are staged as zeros)
+    // ---- step g+1's operands (requested during step g-1) -> the other LDS buffers
 #pragma unroll
     for (int r = 0; r < FS_RPW; r++) {
         const int row = wave + r * FS_NWAVES, pp = c1.h * 16 + row;
-        if (row < 16) {
-            if (pp < M) {
 #pragma unroll
-                for (int e = 0; e < FS_NH; e++) nxt[row * FS_LD + e * 64 + lane] = sv[NX][r][e];
-            } else {
+        for (int e = 0; e < FS_NH; e++) asm volatile("" : "+v"(sv[NX][r][e]));   // consumed on every path
+        if (pp < M) {
 #pragma unroll
-                for (int e = 0; e < FS_NH; e++) nxt[row * FS_LD + e * 64 + lane] = 0.0;
-            }
+            for (int e = 0; e < FS_NH; e++) bnxt[row * FS_LD + e * 64 + lane] = sv[NX][r][e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < FS_NH; e++) bnxt[row * FS_LD + e * 64 + lane] = 0.0;
+        }
+    }
+#pragma unroll
+    for (int pi = 0; pi < FS_PPW; pi++) {
+        const int t = wave + pi * FS_NWAVES, J = c1.pass * FS_TPP + t;
+        const double w = c1.h < J ? 2.0 : 1.0;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            double v = pa[NX][pi][s] * w;
+            asm volatile("" : "+v"(v));                        // consume the load on every path (see above)
+            if (J < nJ && c1.h <= J) anxt[(t * 4 + s) * 64 + lane] = v;
         }
     }
 }
@@ -273,107 +253,93 @@ DEVNI void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W,
         W.Qin[i] = beta * (W.bt[i] - bm);
     }
 #else
-    // T = Sigma * Bt on the FP64 matrix cores (v_mfma_f64_16x16x4_f64), 16 x 16 tiles of T: rows j of
-    // Sigma x features i.  An FS_FT-feature Gram tile is staged through LDS one 16-row k-block at a
-    // time; every wave owns up to two 16-row tiles of Sigma per pass (w and 2 NW - 1 - w: with the
-    // triangular, symmetric schedule both halves cost the same) and multiplies them against all FS_NU
-    // 16-feature sub-tiles, so each Sigma operand fetched from memory feeds FS_NU matrix ops.
-    //   A: lane l holds A[row = l & 15][k = l >> 4];  B: lane l holds B[k = l >> 4][col = l & 15]
-    // No masking in the k-loop: Gram rows >= M are staged as zeros, so Sigma entries beyond the
-    // active block (finite: the workspace is zero-initialised) contribute exactly 0.
-    // B lives in memory (reference argument of a non-inlined function): take register copies once, or
-    // every use in the loop becomes a flat load followed by s_waitcnt vmcnt(0), draining the prefetches.
+    // see fs_step.  B lives in memory (reference argument of a non-inlined function): take register
+    // copies once, or every use in the loop becomes a flat load followed by s_waitcnt vmcnt(0); results
+    // leave through global-address-space pointers for the same reason.
     const int lane = B.lane, wave = uni(B.wave), tid = B.tid, nthr = uni(B.nthr);
-    const gptr_cd Sig = as_global(uni_ptr(W.Sig));
-    const gptr_cd G = as_global(uni_ptr(F.G));
-    // results leave through global-address-space pointers taken once: a flat access inside the loop
-    // (pointer fields of W re-read from memory, flat stores) makes every later wait a full vmcnt(0)
+    const gptr_cc Sig = (gptr_cc)as_global(uni_ptr(W.Sig));
+    const gptr_cc G = (gptr_cc)as_global(uni_ptr(F.G));
     const gptr_d gSin = as_global_rw(uni_ptr(W.Sin)), gQin = as_global_rw(uni_ptr(W.Qin));
     const gptr_cd gbt = as_global(uni_ptr(W.bt));
     double *pool = uni_ptr(B.pool);
-    const lptr_d lt = as_lds(pool);                                              // 2 x 16 x FS_LD staged Gram rows
-    const lptr_i lused = as_lds((int *)(pool + 2 * FS_PC * FS_LD));              // active-set row ids, M <= 2048
-    const lptr_d lmu = as_lds(pool + 2 * FS_PC * FS_LD + 1024);                  // mu, zero-padded to a k-block
-    const lptr_d qred = as_lds(pool + 2 * FS_PC * FS_LD + 1024 + 2064);          // [2 tiles][2][NW][FS_FT] partial sums
+    const lptr_d lb = as_lds(pool);                                         // 2 x 16 x FS_LD   staged Gram k-blocks
+    const lptr_d la = as_lds(pool + 2 * FS_PC * FS_LD);                     // 2 x FS_TPP x 256 staged Sigma panels
+    const lptr_i lused = as_lds((int *)(pool + 2 * FS_PC * FS_LD + 2 * FS_TPP * 256));   // active-set row ids, M <= 2048
+    const lptr_d lmu = as_lds(pool + 2 * FS_PC * FS_LD + 2 * FS_TPP * 256 + 1024);        // mu, zero-padded to a k-block
     K = uni(K); M = uni(M);
     const int ld = uni(W.ld);
     const int nJ = (M + 15) >> 4;
-    const int tiles_per_pass = FS_NWAVES * FS_JTW;
-    const int n_pass = (nJ + tiles_per_pass - 1) / tiles_per_pass;
-    const int row_max = uni(W.cap) - 1;
+    const int n_pass = (nJ + FS_TPP - 1) / FS_TPP;
     const int n_ft = (K + FS_FT - 1) / FS_FT;
     int steps_per_tile = 0;
-    for (int p = 0; p < n_pass; p++) { const int e = p * tiles_per_pass + tiles_per_pass; steps_per_tile += (e < nJ ? e : nJ); }
+    for (int p = 0; p < n_pass; p++) { const int e = p * FS_TPP + FS_TPP; steps_per_tile += (e < nJ ? e : nJ); }
     const int total = n_ft * steps_per_tile;
+    const int l15 = lane & 15, l4 = lane >> 4;
     __syncthreads();
     for (int p = tid; p < nJ * 16; p += nthr) { lused[p < M ? p : 0] = W.rowid[p < M ? p : 0]; lmu[p] = p < M ? W.mu[p] : 0.0; }
-    for (int e = tid; e < 2 * 2 * FS_NWAVES * FS_FT; e += nthr) qred[e] = 0.0;
     __syncthreads();
     FsCur c0, c1, c2;
-    c0.i0 = 0; c0.pass = 0; c0.h = 0; c0.last = (tiles_per_pass < nJ ? tiles_per_pass : nJ) - 1;
-    c1 = c0; fs_advance(c1, n_pass, nJ, tiles_per_pass);
-    c2 = c1; fs_advance(c2, n_pass, nJ, tiles_per_pass);
-    d4 acc[FS_JTW][FS_NU];
+    c0.i0 = 0; c0.pass = 0; c0.h = 0; c0.last = (FS_TPP < nJ ? FS_TPP : nJ) - 1;
+    c1 = c0; fs_advance(c1, n_pass, nJ);
+    c2 = c1; fs_advance(c2, n_pass, nJ);
+    d4 acc[FS_TPP];
 #pragma unroll
-    for (int t = 0; t < FS_JTW; t++)
-#pragma unroll
-        for (int u = 0; u < FS_NU; u++) acc[t][u] = d4{0, 0, 0, 0};
-    double a[2][4][2], sv[2][FS_RPW][FS_NH];
-    {   // pipeline fill: Sigma operands of step 0 (slot 0), Gram rows of step 0 (LDS buffer 0) and of step 1 (slot 1)
-        const int l15 = lane & 15, l4 = lane >> 4;
-        const int jt0 = wave, jt1 = 2 * FS_NWAVES - 1 - wave;
-        int r0 = jt0 * 16 + l15, r1 = jt1 * 16 + l15;
-        r0 = r0 < row_max ? r0 : row_max; r1 = r1 < row_max ? r1 : row_max;
-#pragma unroll
-        for (int sidx = 0; sidx < 4; sidx++) {
-            const int pk = sidx * 4 + l4;
-            const unsigned b0 = (unsigned)((pk < row_max ? pk : row_max) * ld);
-            a[0][sidx][0] = Sig[b0 + r0]; a[0][sidx][1] = Sig[b0 + r1];
-        }
+    for (int t = 0; t < FS_TPP; t++) acc[t] = d4{0, 0, 0, 0};
+    double pa[2][FS_PPW][4], sv[2][FS_RPW][FS_NH];
+    double qsum = 0, msum = 0;
+    {   // pipeline fill: step 0's operands straight to LDS buffers 0, step 1's into ring slot 1
+        const unsigned lane_off = (unsigned)((l4 * ld + l15) * 8);
 #pragma unroll
         for (int r = 0; r < FS_RPW; r++) {
             const int row = wave + r * FS_NWAVES;
             const int p0 = row, p1 = c1.h * 16 + row;
-            const gptr_cd g0 = G + (size_t)lused[p0 < M ? p0 : M - 1] * K;
-            const gptr_cd g1 = G + (size_t)lused[p1 < M ? p1 : M - 1] * K;
+            const gptr_cc g0 = G + (size_t)uni(lused[p0 < M ? p0 : M - 1]) * (size_t)K * 8;
+            const gptr_cc g1 = G + (size_t)uni(lused[p1 < M ? p1 : M - 1]) * (size_t)K * 8;
 #pragma unroll
             for (int e = 0; e < FS_NH; e++) {
                 const int i_0 = e * 64 + lane, i_1 = c1.i0 + e * 64 + lane;
-                const double v0 = g0[i_0 < K ? i_0 : K - 1];
-                sv[1][r][e] = g1[i_1 < K ? i_1 : K - 1];
-                if (row < 16) lt[row * FS_LD + e * 64 + lane] = p0 < M ? v0 : 0.0;
+                const double v0 = *(gptr_cd)(g0 + (unsigned)((i_0 < K ? i_0 : K - 1) * 8));
+                sv[1][r][e] = *(gptr_cd)(g1 + (unsigned)((i_1 < K ? i_1 : K - 1) * 8));
+                lb[row * FS_LD + e * 64 + lane] = p0 < M ? v0 : 0.0;
+            }
+        }
+#pragma unroll
+        for (int pi = 0; pi < FS_PPW; pi++) {
+            const int t = wave + pi * FS_NWAVES;
+            const int J1 = c1.pass * FS_TPP + t;
+            const bool on0 = t < nJ, on1 = J1 < nJ && c1.h <= J1;
+            const unsigned o0 = on0 ? (unsigned)(t * 16 * 8) + lane_off : 0u, st0 = on0 ? (unsigned)(4 * ld * 8) : 0u;
+            const unsigned o1 = on1 ? (unsigned)((c1.h * 16 * ld + J1 * 16) * 8) + lane_off : 0u, st1 = on1 ? (unsigned)(4 * ld * 8) : 0u;
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const double v0 = *(gptr_cd)(Sig + (o0 + s * st0));
+                pa[1][pi][s] = *(gptr_cd)(Sig + (o1 + s * st1));
+                if (on0) la[(t * 4 + s) * 64 + lane] = v0 * (0 < t ? 2.0 : 1.0);
             }
         }
     }
-    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): nothing pending at loop entry (see fs_step); the compiler tracks this form
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): nothing pending at loop entry; the compiler tracks this form
     __syncthreads();
-    // After the barrier that ends the last step of a feature tile, the first FS_FT threads sum the
-    // per-wave partials of that tile (qred is double-buffered by tile parity) while the other waves
-    // already run the next tile.
+    // After the last step of a feature tile every wave holds the sums of its 16 features, spread over
+    // the four row groups of the accumulator layout: two xor-shuffles, then lanes 0..15 write them.
 #define FS_FINISH_TILE(cc)                                                                                           \
         if ((cc).h == (cc).last && (cc).pass == n_pass - 1) {                                                        \
-            const lptr_d qb = qred + (((cc).i0 / FS_FT) & 1) * (2 * FS_NWAVES * FS_FT);                              \
-            if (tid < FS_FT) {                                                                                       \
-                const int i = (cc).i0 + tid;                                                                         \
-                double q = 0, m = 0;                                                                                 \
-                for (int w = 0; w < FS_NWAVES; w++) {                                                                \
-                    q += qb[w * FS_FT + tid]; m += qb[(FS_NWAVES + w) * FS_FT + tid];                                \
-                    qb[w * FS_FT + tid] = 0.0; qb[(FS_NWAVES + w) * FS_FT + tid] = 0.0;                              \
-                }                                                                                                    \
-                if (i < K) { gSin[i] = beta - beta * q * beta; gQin[i] = beta * (gbt[i] - m); }                      \
-            }                                                                                                        \
+            double q = qsum, m = msum;                                                                               \
+            q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);                                                  \
+            m += __shfl_xor(m, 16, 64); m += __shfl_xor(m, 32, 64);                                                  \
+            const int i = (cc).i0 + 16 * wave + l15;                                                                 \
+            if (lane < 16 && i < K) { gSin[i] = beta - beta * q * beta; gQin[i] = beta * (gbt[i] - m); }             \
+            qsum = 0; msum = 0;                                                                                      \
         }
 #define FS_STEP(CURSLOT, gg)                                                                                         \
         {                                                                                                            \
-            const lptr_d cur = lt + ((gg) & 1) * (FS_PC * FS_LD);                                                    \
-            const lptr_d nxt = lt + (((gg) + 1) & 1) * (FS_PC * FS_LD);                                              \
-            const lptr_d qb = qred + ((c0.i0 / FS_FT) & 1) * (2 * FS_NWAVES * FS_FT);                                \
-            fs_step<CURSLOT>((gptr_cc)Sig, (gptr_cc)G, lused, lmu, cur, nxt, qb, ld, c0, c1, c2, tiles_per_pass, nJ, \
-                             M, K,                                                                                   \
-                             wave, lane, a, sv, acc);                                                                \
-            __syncthreads();                                                                                         \
+            const int cb = (gg) & 1, nb = cb ^ 1;                                                                    \
+            fs_step<CURSLOT>(Sig, G, lused, lmu, lb + cb * (FS_PC * FS_LD), lb + nb * (FS_PC * FS_LD),               \
+                             la + cb * (FS_TPP * 256), la + nb * (FS_TPP * 256), ld, c0, c1, c2, nJ, M, K, wave,     \
+                             lane, pa, sv, acc, qsum, msum);                                                         \
             FS_FINISH_TILE(c0)                                                                                       \
-            c0 = c1; c1 = c2; fs_advance(c2, n_pass, nJ, tiles_per_pass);                                            \
+            __syncthreads();                                                                                         \
+            c0 = c1; c1 = c2; fs_advance(c2, n_pass, nJ);                                                            \
         }
     // whole pairs of steps without any skip path inside the loop (a skipped step would leave its
     // predecessor's prefetch pending on the back edge: static s_waitcnt vmcnt(0)); then the odd tail
