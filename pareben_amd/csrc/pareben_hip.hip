@@ -766,13 +766,20 @@ extern "C" int pareben_ctx_run(pareben_ctx *c, int n_cells, const double *alpha,
     if (!c || n_cells < 1 || !alpha || !lambda || !fold_err) return fail(PAREBEN_EINVAL, "bad argument");
     HIPCHK(hipSetDevice(c->device));
     const int nF = c->n_folds, n_units = n_cells * nF;
-    // heaviest first: small lambda (then small alpha) fits carry the largest active sets
-    std::vector<int> cells(n_cells);
-    std::iota(cells.begin(), cells.end(), 0);
-    std::stable_sort(cells.begin(), cells.end(), [&](int a, int b) {
-        if (lambda[a] != lambda[b]) return lambda[a] < lambda[b];
+    // Queue order.  Cost is far from monotone in lambda: nothing happens above the lambda where the first
+    // features enter, the heaviest fits sit right at that sparse-to-dense transition (its position moves
+    // with alpha), and below it the cost is flat -- except for the occasional very long add/delete
+    // trajectory at the smallest lambdas.  So the queue runs outside-in over the lambda-sorted cells,
+    // three cells from the large-lambda end for each one from the small-lambda end: the large end is
+    // consumed almost for free and reaches the transition early, the small end starts its long fits
+    // at once, and the uniform middle packs the tail.
+    std::vector<int> sorted(n_cells), cells(n_cells);
+    std::iota(sorted.begin(), sorted.end(), 0);
+    std::stable_sort(sorted.begin(), sorted.end(), [&](int a, int b) {
+        if (lambda[a] != lambda[b]) return lambda[a] > lambda[b];
         return alpha[a] < alpha[b];
     });
+    for (int k = 0, lo = 0, hi = n_cells - 1; k < n_cells; k++) cells[k] = ((k & 3) == 3) ? sorted[hi--] : sorted[lo++];
     std::vector<int> order(n_units);
     for (int k = 0; k < n_cells; k++) for (int f = 0; f < nF; f++) order[k * nF + f] = cells[k] * nF + f;
 

@@ -24,6 +24,8 @@ with pareben_amd.Context(X, y, fid, a.nfolds) as ctx:
     E, st, cnt = ctx.run(alpha, lam)
     print("timing", ctx.last_timing(), ctx.launch_info())
 ph = np.fromfile(path, dtype=np.int64).reshape(-1, 8).astype(np.float64)
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+np.savez(os.path.join(ROOT, "gpurun_out", "phase_dump.npz"), ph=ph, cnt=cnt, alpha=alpha, lam=lam)
 names = ["fullstat_features", "fullstat_rest(incl in total only)", "delta_ml+collect", "actions", "noise", "spd_inverse", "final_rest", "total"]
 tot = ph[:, 7].sum()
 print("sum of per-fit wall ticks (100 MHz): %.3f s over %d fits" % (tot / 1e8, len(ph)))
