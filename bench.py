@@ -66,14 +66,30 @@ def main():
     # PAREBEN_BENCH_BACKEND=gloo + PAREBEN_BENCH_ONE_DEVICE=1 rehearse the N > 1 path on a one-GPU box
     backend = os.environ.get("PAREBEN_BENCH_BACKEND", "nccl")
     dev_index = 0 if os.environ.get("PAREBEN_BENCH_ONE_DEVICE") else local_rank
-    if world > 1:
+    # PAREBEN_BENCH_FORCE_DIST=1 initialises the process group (and takes the all-gather path) even at
+    # world size 1, so the RCCL code path can be exercised on a one-GPU box
+    use_dist = world > 1 or bool(os.environ.get("PAREBEN_BENCH_FORCE_DIST"))
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(dev_index)
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        # RCCL prints a version banner on stdout when the first communicator comes up; stdout must
+        # carry exactly one JSON line, so the banner is sent to stderr (fd-level, it is printed from C)
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.barrier()
+            if backend == "nccl":
+                torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
     else:
         dist = None
         torch.cuda.set_device(0)
@@ -94,7 +110,7 @@ def main():
 
     def step():
         err, st, cnt = ctx.run(alpha[mine], lam[mine])
-        if world > 1:
+        if use_dist:
             fold_err, status = all_gather_cells(mine, err, st, n_cells, nF)
         else:
             fold_err = np.empty((n_cells, nF)); status = np.empty((n_cells, nF), dtype=np.int32)
