@@ -25,6 +25,11 @@
 #pragma once
 #include "blk.h"
 #include "types.h"
+#ifdef PAREBEN_HOST_EMUL
+#define FS_FT_OR_ONE 128
+#else
+#define FS_FT_OR_ONE FS_FT
+#endif
 #if defined(PAREBEN_HOST_EMUL) && defined(PAREBEN_TRACE)
 #include <stdio.h>
 #define GM_TRACE(...) fprintf(stderr, __VA_ARGS__)
@@ -54,6 +59,8 @@ struct GmScalars {
     int M;             // active-set size
     int status;
     FitCounters *c;    // one copy per workgroup (LDS), updated by thread 0 only
+    const FsShare *share = nullptr;   // shared full-stat passes (device only; null = off)
+    int fold = 0;
 };
 #define CNT(stmt) do { if (B.tid == 0) { FitCounters &c = *S.c; stmt; } } while (0)
 
@@ -236,10 +243,11 @@ DEV void fs_step(gptr_cc Sig, gptr_cc G, lptr_i lused, lptr_d lmu, lptr_d bcur, 
 // run time; lanes run over features (coalesced Gram rows), each wavefront owns
 // 8 rows of Sigma per pass and the Gram tile is staged through LDS once per pass.
 DEVNI void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W, int K, int M,
-                              double beta)
+                              double beta, int tile0, int tile1)
 {
 #ifdef PAREBEN_HOST_EMUL
     const int ld = W.ld;
+    (void)tile0; (void)tile1;
     for (int i = 0; i < K; i++) {
         double quad = 0, bm = 0;
         for (int j = 0; j < M; j++) {
@@ -270,7 +278,8 @@ DEVNI void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W,
     const int ld = uni(W.ld);
     const int nJ = (M + 15) >> 4;
     const int n_pass = (nJ + FS_TPP - 1) / FS_TPP;
-    const int n_ft = (K + FS_FT - 1) / FS_FT;
+    const int n_ft = uni(tile1) - uni(tile0);                               // feature tiles tile0 .. tile1-1 of the call
+    const int i_begin = uni(tile0) * FS_FT;
     int steps_per_tile = 0;
     for (int p = 0; p < n_pass; p++) { const int e = p * FS_TPP + FS_TPP; steps_per_tile += (e < nJ ? e : nJ); }
     const int total = n_ft * steps_per_tile;
@@ -279,7 +288,7 @@ DEVNI void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W,
     for (int p = tid; p < nJ * 16; p += nthr) { lused[p < M ? p : 0] = W.rowid[p < M ? p : 0]; lmu[p] = p < M ? W.mu[p] : 0.0; }
     __syncthreads();
     FsCur c0, c1, c2;
-    c0.i0 = 0; c0.pass = 0; c0.h = 0; c0.last = (FS_TPP < nJ ? FS_TPP : nJ) - 1;
+    c0.i0 = i_begin; c0.pass = 0; c0.h = 0; c0.last = (FS_TPP < nJ ? FS_TPP : nJ) - 1;
     c1 = c0; fs_advance(c1, n_pass, nJ);
     c2 = c1; fs_advance(c2, n_pass, nJ);
     d4 acc[FS_TPP];
@@ -297,7 +306,7 @@ DEVNI void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W,
             const gptr_cc g1 = G + (size_t)uni(lused[p1 < M ? p1 : M - 1]) * (size_t)K * 8;
 #pragma unroll
             for (int e = 0; e < FS_NH; e++) {
-                const int i_0 = e * 64 + lane, i_1 = c1.i0 + e * 64 + lane;
+                const int i_0 = i_begin + e * 64 + lane, i_1 = c1.i0 + e * 64 + lane;
                 const double v0 = *(gptr_cd)(g0 + (unsigned)((i_0 < K ? i_0 : K - 1) * 8));
                 sv[1][r][e] = *(gptr_cd)(g1 + (unsigned)((i_1 < K ? i_1 : K - 1) * 8));
                 lb[row * FS_LD + e * 64 + lane] = p0 < M ? v0 : 0.0;
@@ -355,6 +364,91 @@ DEVNI void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W,
     blk_sync(B);
 }
 
+// ---- shared full-stat passes ------------------------------------------------------------------
+// A fit is one workgroup, and the heaviest fits of a grid take tens of times the median; once the
+// work queue is drained the workgroups that are out of fits would sit idle while those finish.  The
+// full-stat pass (half of a heavy fit's time) is independent per feature tile, so in that phase of the
+// launch an owner OPENS each pass (FsJob): idle workgroups claim chunks of feature tiles by
+// compare-and-swap on (epoch, next tile), run the same fs_step pipeline on the owner's Sigma / mu /
+// row ids in HBM and write S_in / Q_in for their tiles; the owner works on its own pass too and waits
+// for the chunk count.  Results do not depend on who computed a tile (same code, same order).
+// Visibility follows the guide's hand-off recipe both ways: stores drained by every wave, barrier,
+// one agent-scope release, then a relaxed atomic; consumers read the atomic relaxed, then one
+// agent-scope acquire + s_waitcnt vmcnt(0) + barrier before plain loads.  Nobody waits while holding
+// a chunk, so every wait ends; the owner's wait is bounded anyway and flags the fit if it expires.
+#ifndef PAREBEN_HOST_EMUL
+#define FS_CHUNK 4
+#define AT_LOAD(p) __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define AT_STORE(p, v) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define AT_ADD(p, v) __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+DEV bool fs_epoch_open(unsigned long long w) { return (w >> 32) & 1; }
+// thread 0 only: first tile of the claimed chunk, or -1 when the pass is closed / fully handed out
+DEV int fs_claim(FsJob *job, int n_tiles)
+{
+    for (;;) {
+        unsigned long long w = AT_LOAD(&job->word);
+        if (!fs_epoch_open(w) || (int)(unsigned)w >= n_tiles) return -1;
+        if (__hip_atomic_compare_exchange_strong(&job->word, &w, w + FS_CHUNK, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            return (int)(unsigned)w;
+    }
+}
+#endif
+
+DEVNI void gm_fullstat_pass(const Blk &B, const FoldDev &F, const GmWork &W, int K, int M, double beta, GmScalars &S)
+{
+    const int n_tiles = (K + FS_FT_OR_ONE - 1) / FS_FT_OR_ONE;
+#ifdef PAREBEN_HOST_EMUL
+    gm_fullstat_features(B, F, W, K, M, beta, 0, n_tiles);
+#else
+    const FsShare *sh = S.share;
+    bool open = false;
+    if (sh && sh->jobs && M >= 48 && n_tiles >= 4 * FS_CHUNK) {
+        __syncthreads();
+        if (B.tid == 0) B.ired[0] = AT_LOAD(sh->queue) >= sh->n_units;     // queue drained: others are idle
+        __syncthreads();
+        open = B.ired[0] != 0;
+        __syncthreads();
+    }
+    if (!open) { gm_fullstat_features(B, F, W, K, M, beta, 0, n_tiles); return; }
+    FsJob *job = sh->jobs + sh->self;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // Sigma, mu, row ids, bt: every wave drains its stores
+    __syncthreads();
+    if (B.tid == 0) {
+        AT_STORE(&job->done, 0); AT_STORE(&job->fold, S.fold); AT_STORE(&job->M, M); AT_STORE(&job->n_tiles, n_tiles);
+        __hip_atomic_store(&job->beta, beta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long w = AT_LOAD(&job->word);
+        AT_STORE(&job->word, ((w >> 32) + 1) << 32);           // odd epoch, next tile 0: open
+    }
+    __syncthreads();
+    int mine = 0;
+    for (;;) {
+        if (B.tid == 0) B.ired[0] = fs_claim(job, n_tiles);
+        __syncthreads();
+        const int c = B.ired[0];
+        __syncthreads();
+        if (c < 0) break;
+        gm_fullstat_features(B, F, W, K, M, beta, c, c + FS_CHUNK < n_tiles ? c + FS_CHUNK : n_tiles);
+        mine++;
+    }
+    if (B.tid == 0) {
+        const int total = (n_tiles + FS_CHUNK - 1) / FS_CHUNK;
+        AT_ADD(&job->done, mine);
+        long spins = 0;
+        while (AT_LOAD(&job->done) < total && spins < 200000000L) { __builtin_amdgcn_s_sleep(8); spins++; }
+        B.ired[0] = AT_LOAD(&job->done) >= total;
+        const unsigned long long w = AT_LOAD(&job->word);
+        AT_STORE(&job->word, ((w >> 32) + 1) << 32);           // even epoch: closed
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // the helpers' S_in / Q_in
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (!B.ired[0]) S.status |= ST_ABORT;
+    __syncthreads();
+#endif
+}
+
 // Full statistics, MainEff.c:1209-1341 (Q3: gamma[0] is left alone).
 DEV void gm_fullstat(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScalars &S,
                      bool very_first)
@@ -381,7 +475,7 @@ DEV void gm_fullstat(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmS
 #if defined(PAREBEN_PHASE_TIMERS) && !defined(PAREBEN_HOST_EMUL)
         const long long ck0 = (B.tid == 0) ? (long long)clock64() : 0;
 #endif
-        gm_fullstat_features(B, F, W, K, M, beta);
+        gm_fullstat_pass(B, F, W, K, M, beta, S);
 #if defined(PAREBEN_PHASE_TIMERS) && !defined(PAREBEN_HOST_EMUL)
         if (B.tid == 0) S.ph[PH_FS_REST] += (long long)clock64() - ck0;     // shader-clock ticks of the same span
 #endif

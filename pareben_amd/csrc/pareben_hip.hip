@@ -291,6 +291,8 @@ struct CvParams {
     size_t ws_stride, offK, offSig, offM;
     int K, cap, n_folds, n_units;
     int priv_base0, priv_rows;         // lazy Gram mode: private rows of workgroup b start at priv_base0 + b * priv_rows
+    FsJob *jobs;                       // shared full-stat passes (gm_fit.h); null = off
+    int *active;
     GmVariant v;
 };
 
@@ -322,6 +324,65 @@ __device__ inline void store_counters(long long *dst, const FitCounters &c)
     dst[9] = c.m_final; dst[10] = c.m_max; dst[11] = c.status;
 }
 
+// A workgroup that found the work queue empty helps the fits still running: it scans the job board (64
+// owners per load with wave 0), claims a chunk of feature tiles of an open full-stat pass and runs it on
+// the owner's state (gm_fit.h, "shared full-stat passes").  Leaves when no workgroup owns a fit any more.
+__device__ void fs_help_loop(const Blk &B, const FsShare &sh, int K)
+{
+    __shared__ int s_pick[4];
+    if (!sh.jobs) return;
+    __syncthreads();
+    if (threadIdx.x == 0) AT_ADD(sh.active, -1);
+    for (;;) {
+        __syncthreads();
+        if (B.wave == 0) {
+            int owner = -1, first = -1;
+            const int quit = AT_LOAD(sh.active) <= 0;
+            for (int base = 0; !quit && owner < 0 && base < sh.n_blocks; base += 64) {
+                const int b = base + B.lane;
+                unsigned long long w = b < sh.n_blocks ? AT_LOAD(&sh.jobs[b].word) : 0ull;
+                const int nt = (b < sh.n_blocks && fs_epoch_open(w)) ? AT_LOAD(&sh.jobs[b].n_tiles) : 0;
+                unsigned long long cand = __ballot(fs_epoch_open(w) && (int)(unsigned)w < nt);
+                while (cand && owner < 0) {
+                    const int l = __ffsll((long long)cand) - 1;
+                    cand &= cand - 1;
+                    int got = -1;
+                    if (B.lane == l) {
+                        unsigned long long e = w;
+                        if (__hip_atomic_compare_exchange_strong(&sh.jobs[b].word, &e, w + FS_CHUNK, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                                 __HIP_MEMORY_SCOPE_AGENT)) got = (int)(unsigned)w;
+                    }
+                    got = __shfl(got, l, 64);
+                    if (got >= 0) { owner = base + l; first = got; }
+                }
+            }
+            if (B.lane == 0) { s_pick[0] = owner; s_pick[1] = first; s_pick[2] = quit; }
+        }
+        __syncthreads();
+        const int owner = s_pick[0], first = s_pick[1], quit = s_pick[2];
+        if (quit) break;
+        if (owner < 0) { __builtin_amdgcn_s_sleep(127); continue; }
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");       // the owner's Sigma, mu, row ids, bt
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        FsJob *job = sh.jobs + owner;
+        const int M = AT_LOAD(&job->M), fold = AT_LOAD(&job->fold), n_tiles = AT_LOAD(&job->n_tiles);
+        const double beta = __hip_atomic_load(&job->beta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const GmWork Wo = ws_carve(sh.ws + (size_t)owner * sh.ws_stride, K, sh.cap, sh.offK, sh.offSig, sh.offM);
+        const FoldDev Fo = sh.folds[fold];
+        gm_fullstat_features(B, Fo, Wo, K, M, beta, first, first + FS_CHUNK < n_tiles ? first + FS_CHUNK : n_tiles);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // every wave drains its S_in / Q_in stores
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            AT_ADD(&job->done, 1);
+        }
+    }
+}
+
 __global__ __launch_bounds__(FIT_THREADS) void gm_cv_kernel(CvParams P)
 {
     __shared__ int s_unit;
@@ -331,6 +392,10 @@ __global__ __launch_bounds__(FIT_THREADS) void gm_cv_kernel(CvParams P)
     GmWork W = ws_carve(P.ws + (size_t)blockIdx.x * P.ws_stride, P.K, P.cap, P.offK, P.offSig, P.offM);
     W.priv_rows = P.priv_rows;
     W.priv_base = P.priv_base0 + (int)blockIdx.x * P.priv_rows;
+    FsShare sh;
+    sh.jobs = P.jobs; sh.active = P.active; sh.queue = P.queue; sh.n_units = P.n_units; sh.n_blocks = gridDim.x;
+    sh.self = blockIdx.x; sh.ws = P.ws; sh.ws_stride = P.ws_stride; sh.offK = P.offK; sh.offSig = P.offSig; sh.offM = P.offM;
+    sh.folds = P.folds; sh.cap = P.cap;
     for (;;) {
         __syncthreads();
         if (threadIdx.x == 0) s_unit = atomicAdd(P.queue, 1);
@@ -344,6 +409,8 @@ __global__ __launch_bounds__(FIT_THREADS) void gm_cv_kernel(CvParams P)
         S.c = &s_cnt;
         S.ph = s_ph;
         S.v = P.v;
+        S.share = &sh;
+        S.fold = f;
 #ifdef PAREBEN_PHASE_TIMERS
         if (threadIdx.x < 8) s_ph[threadIdx.x] = 0;
         __syncthreads();
@@ -363,6 +430,7 @@ __global__ __launch_bounds__(FIT_THREADS) void gm_cv_kernel(CvParams P)
             if (P.counters) store_counters(P.counters + (size_t)unit * PAREBEN_NCOUNTERS, s_cnt);
         }
     }
+    fs_help_loop(B, sh, P.K);
 }
 
 struct BmCvParams {
@@ -801,8 +869,10 @@ extern "C" int pareben_ctx_run(pareben_ctx *c, int n_cells, const double *alpha,
     double *d_alpha = nullptr, *d_lambda = nullptr, *d_err = nullptr;
     int *d_order = nullptr, *d_queue = nullptr, *d_status = nullptr;
     long long *d_cnt = nullptr, *d_phase = nullptr;
+    FsJob *d_jobs = nullptr; int *d_active = nullptr;
+    int act_host[4] = {0, 0, 0, 0};                             // lives until the stream is synchronised below
     const char *phase_path = getenv("PAREBEN_PHASE_DUMP");     // diagnostic build only
-    auto cleanup = [&]() { hipFree(d_phase); hipFree(d_alpha); hipFree(d_lambda); hipFree(d_err); hipFree(d_order); hipFree(d_queue); hipFree(d_status); hipFree(d_cnt); };
+    auto cleanup = [&]() { hipFree(d_jobs); hipFree(d_active); hipFree(d_phase); hipFree(d_alpha); hipFree(d_lambda); hipFree(d_err); hipFree(d_order); hipFree(d_queue); hipFree(d_status); hipFree(d_cnt); };
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(PAREBEN_EHIP, #x, e_); } } while (0)
     CK(dmalloc(&d_alpha, (size_t)n_cells)); CK(dmalloc(&d_lambda, (size_t)n_cells));
     CK(dmalloc(&d_err, (size_t)n_units)); CK(dmalloc(&d_order, (size_t)n_units));
@@ -817,6 +887,13 @@ extern "C" int pareben_ctx_run(pareben_ctx *c, int n_cells, const double *alpha,
     CK(hipMemcpyAsync(d_lambda, lambda, sizeof(double) * n_cells, hipMemcpyHostToDevice, c->stream));
     CK(hipMemcpyAsync(d_order, order.data(), sizeof(int) * n_units, hipMemcpyHostToDevice, c->stream));
     CK(hipMemsetAsync(d_queue, 0, sizeof(int), c->stream));
+    const char *share_env = getenv("PAREBEN_SHARE");            // PAREBEN_SHARE=0: no shared full-stat passes (A/B tests)
+    if (!binom && !(share_env && share_env[0] == '0')) {
+        CK(dmalloc(&d_jobs, (size_t)blocks)); CK(dmalloc(&d_active, (size_t)4));
+        CK(hipMemsetAsync(d_jobs, 0, sizeof(FsJob) * (size_t)blocks, c->stream));
+        act_host[0] = blocks;
+        CK(hipMemcpyAsync(d_active, act_host, sizeof act_host, hipMemcpyHostToDevice, c->stream));
+    }
     CK(hipMemsetAsync(d_err, 0xFF, sizeof(double) * n_units, c->stream));       // NaN-poison
     CK(hipMemsetAsync(d_status, 0xFF, sizeof(int) * n_units, c->stream));
 
@@ -831,6 +908,7 @@ extern "C" int pareben_ctx_run(pareben_ctx *c, int n_cells, const double *alpha,
     P.ws_stride = c->L.bytes; P.offK = c->L.offK; P.offSig = c->L.offSig; P.offM = c->L.offM;
     P.K = c->kfull; P.cap = c->cap; P.n_folds = nF; P.n_units = n_units; P.v = c->variant;
     P.priv_rows = c->priv_rows; P.priv_base0 = nF * c->pool_rows;
+    P.jobs = d_jobs; P.active = d_active;
     if (binom) {
         BmCvParams Q;
         Q.folds = c->d_folds; Q.alpha = d_alpha; Q.lambda = d_lambda; Q.order = d_order; Q.queue = d_queue;
@@ -999,7 +1077,7 @@ __global__ __launch_bounds__(FIT_THREADS) void diag_fullstat_kernel(DiagParams P
     F.G = P.G;
     for (int i = threadIdx.x; i < P.M; i += blockDim.x) { W.rowid[i] = i; W.used[i] = i; W.mu[i] = 0.001 * i; }
     __syncthreads();
-    for (int r = 0; r < P.reps; r++) gm_fullstat_features(B, F, W, P.K, P.M, 1.0);
+    for (int r = 0; r < P.reps; r++) gm_fullstat_features(B, F, W, P.K, P.M, 1.0, 0, (P.K + FS_FT - 1) / FS_FT);
 }
 extern "C" int pareben_diag_fullstat(int M, int K, int blocks, int reps, double *ms_out)
 {

@@ -64,3 +64,25 @@ struct GmWork {
     double *e;                                             // max(N) scratch
     int cap, ld;
 };
+
+// One full-stat pass offered to idle workgroups (gm_fit.h, "shared full-stat passes").  `word` packs
+// (epoch << 32) | next_tile: odd epoch = open; tiles are claimed by compare-and-swap on the whole word,
+// so a claim always belongs to the pass that was open when it was made.
+struct FsJob {
+    unsigned long long word;
+    int done;              // chunks finished (by anyone)
+    int fold, M, n_tiles;
+    int pad[2];
+    double beta;
+    double pad2[3];        // one 64-byte line per job
+};
+struct FsShare {           // null jobs = sharing off
+    FsJob *jobs;           // one per workgroup of the launch
+    int *active;           // workgroups that still own a fit or may pull one from the queue
+    const int *queue;      // work-queue head (>= n_units: drained)
+    int n_units, n_blocks, self;
+    char *ws;              // workspace base / stride of the launch: a helper carves the owner's slot
+    size_t ws_stride, offK, offSig, offM;
+    const FoldDev *folds;
+    int cap;
+};
