@@ -364,58 +364,61 @@ DEVNI void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W,
     blk_sync(B);
 }
 
-// ---- shared full-stat passes ------------------------------------------------------------------
+// ---- shared phases ------------------------------------------------------------------------------
 // A fit is one workgroup, and the heaviest fits of a grid take tens of times the median; once the
 // work queue is drained the workgroups that are out of fits would sit idle while those finish.  The
-// full-stat pass (half of a heavy fit's time) is independent per feature tile, so in that phase of the
-// launch an owner OPENS each pass (FsJob): idle workgroups claim chunks of feature tiles by
-// compare-and-swap on (epoch, next tile), run the same fs_step pipeline on the owner's Sigma / mu /
-// row ids in HBM and write S_in / Q_in for their tiles; the owner works on its own pass too and waits
-// for the chunk count.  Results do not depend on who computed a tile (same code, same order).
+// full-stat pass (half of a heavy fit's time) and the K x M mat-vec of every action are independent
+// per feature, so in that phase of the launch an owner OPENS each of them (FsJob): idle workgroups
+// claim chunks of 128-feature tiles by compare-and-swap on (epoch, next tile), run the same code on
+// the owner's state in HBM (Sigma / mu / row ids, or the action's vector) and write S_in / Q_in for
+// their features; the owner works on its own job too and waits for the chunk count.  Results do not
+// depend on who computed a feature (same code, same order).
 // Visibility follows the guide's hand-off recipe both ways: stores drained by every wave, barrier,
 // one agent-scope release, then a relaxed atomic; consumers read the atomic relaxed, then one
 // agent-scope acquire + s_waitcnt vmcnt(0) + barrier before plain loads.  Nobody waits while holding
 // a chunk, so every wait ends; the owner's wait is bounded anyway and flags the fit if it expires.
 #ifndef PAREBEN_HOST_EMUL
-#define FS_CHUNK 4
+#define FS_CHUNK 4         // tiles per claim, full-stat pass
+#define SQ_CHUNK 8         // tiles per claim, action mat-vec (1024 features = one pair per thread)
 #define AT_LOAD(p) __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define AT_STORE(p, v) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define AT_ADD(p, v) __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 DEV bool fs_epoch_open(unsigned long long w) { return (w >> 32) & 1; }
-// thread 0 only: first tile of the claimed chunk, or -1 when the pass is closed / fully handed out
-DEV int fs_claim(FsJob *job, int n_tiles)
+DEV int job_chunk(int kind) { return kind == JOB_SQ ? SQ_CHUNK : FS_CHUNK; }
+// thread 0 only: first tile of the claimed chunk, or -1 when the job is closed / fully handed out
+DEV int fs_claim(FsJob *job, int n_tiles, int chunk)
 {
     for (;;) {
         unsigned long long w = AT_LOAD(&job->word);
         if (!fs_epoch_open(w) || (int)(unsigned)w >= n_tiles) return -1;
-        if (__hip_atomic_compare_exchange_strong(&job->word, &w, w + FS_CHUNK, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        if (__hip_atomic_compare_exchange_strong(&job->word, &w, w + chunk, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
             return (int)(unsigned)w;
     }
 }
-#endif
-
-DEVNI void gm_fullstat_pass(const Blk &B, const FoldDev &F, const GmWork &W, int K, int M, double beta, GmScalars &S)
+// Owner side.  Returns false when sharing is off / not worth it (the caller then does the whole phase);
+// otherwise opens the job, runs work(tile0, tile1) on the chunks it claims itself, waits for the rest.
+template <class Work>
+DEV bool job_share(const Blk &B, GmScalars &S, int kind, int M, int n_tiles, double beta, int mode, int rid, double c1,
+                   double c2, Work work)
 {
-    const int n_tiles = (K + FS_FT_OR_ONE - 1) / FS_FT_OR_ONE;
-#ifdef PAREBEN_HOST_EMUL
-    gm_fullstat_features(B, F, W, K, M, beta, 0, n_tiles);
-#else
     const FsShare *sh = S.share;
-    bool open = false;
-    if (sh && sh->jobs && M >= 48 && n_tiles >= 4 * FS_CHUNK) {
-        __syncthreads();
-        if (B.tid == 0) B.ired[0] = AT_LOAD(sh->queue) >= sh->n_units;     // queue drained: others are idle
-        __syncthreads();
-        open = B.ired[0] != 0;
-        __syncthreads();
-    }
-    if (!open) { gm_fullstat_features(B, F, W, K, M, beta, 0, n_tiles); return; }
+    const int chunk = job_chunk(kind);
+    if (!(sh && sh->jobs) || n_tiles < 4 * chunk) return false;
+    __syncthreads();
+    if (B.tid == 0) B.ired[0] = AT_LOAD(sh->queue) >= sh->n_units;         // queue drained: others are idle
+    __syncthreads();
+    const bool open = B.ired[0] != 0;
+    __syncthreads();
+    if (!open) return false;
     FsJob *job = sh->jobs + sh->self;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // Sigma, mu, row ids, bt: every wave drains its stores
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // what the phase reads: every wave drains its stores
     __syncthreads();
     if (B.tid == 0) {
         AT_STORE(&job->done, 0); AT_STORE(&job->fold, S.fold); AT_STORE(&job->M, M); AT_STORE(&job->n_tiles, n_tiles);
+        AT_STORE(&job->kind, kind); AT_STORE(&job->mode, mode); AT_STORE(&job->rid, rid);
         __hip_atomic_store(&job->beta, beta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&job->c1, c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&job->c2, c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned long long w = AT_LOAD(&job->word);
@@ -424,19 +427,19 @@ DEVNI void gm_fullstat_pass(const Blk &B, const FoldDev &F, const GmWork &W, int
     __syncthreads();
     int mine = 0;
     for (;;) {
-        if (B.tid == 0) B.ired[0] = fs_claim(job, n_tiles);
+        if (B.tid == 0) B.ired[0] = fs_claim(job, n_tiles, chunk);
         __syncthreads();
         const int c = B.ired[0];
         __syncthreads();
         if (c < 0) break;
-        gm_fullstat_features(B, F, W, K, M, beta, c, c + FS_CHUNK < n_tiles ? c + FS_CHUNK : n_tiles);
+        work(c, c + chunk < n_tiles ? c + chunk : n_tiles);
         mine++;
     }
     if (B.tid == 0) {
-        const int total = (n_tiles + FS_CHUNK - 1) / FS_CHUNK;
+        const int total = (n_tiles + chunk - 1) / chunk;
         AT_ADD(&job->done, mine);
         long spins = 0;
-        while (AT_LOAD(&job->done) < total && spins < 200000000L) { __builtin_amdgcn_s_sleep(8); spins++; }
+        while (AT_LOAD(&job->done) < total && spins < 200000000L) { __builtin_amdgcn_s_sleep(4); spins++; }
         B.ired[0] = AT_LOAD(&job->done) >= total;
         const unsigned long long w = AT_LOAD(&job->word);
         AT_STORE(&job->word, ((w >> 32) + 1) << 32);           // even epoch: closed
@@ -446,7 +449,18 @@ DEVNI void gm_fullstat_pass(const Blk &B, const FoldDev &F, const GmWork &W, int
     __syncthreads();
     if (!B.ired[0]) S.status |= ST_ABORT;
     __syncthreads();
+    return true;
+}
 #endif
+
+DEVNI void gm_fullstat_pass(const Blk &B, const FoldDev &F, const GmWork &W, int K, int M, double beta, GmScalars &S)
+{
+    const int n_tiles = (K + FS_FT_OR_ONE - 1) / FS_FT_OR_ONE;
+#ifndef PAREBEN_HOST_EMUL
+    if (M >= 48 && job_share(B, S, JOB_FULLSTAT, M, n_tiles, beta, 0, -1, 0.0, 0.0,
+                             [&](int t0, int t1) { gm_fullstat_features(B, F, W, K, M, beta, t0, t1); })) return;
+#endif
+    gm_fullstat_features(B, F, W, K, M, beta, 0, n_tiles);
 }
 
 // Full statistics, MainEff.c:1209-1341 (Q3: gamma[0] is left alone).
@@ -600,24 +614,92 @@ DEV void gm_sq_apply(const GmWork &W, int mode, double beta, double c1, double c
     }
 }
 
-// a[i] = sum_j G[used[j], i] * vec[j] for all features, fused with the S_in/Q_in update that
-// consumes it.
-DEVNI void gm_sq_update(const Blk &B, const FoldDev &F, const GmWork &W, int K, int M, const double *vec,
-                        int mode, double beta, double c1, double c2, const double *newrow)
+#ifndef PAREBEN_HOST_EMUL
+// Features [f0, f1) (f0 even, f1 <= K & ~1) of the K x M mat-vec over Gram rows + the S/Q update.  Row ids
+// and `vec` are already staged in LDS.  Every thread owns SQ_Q PAIRS of adjacent features and fetches
+// each pair with one 16-byte load (row base in SGPRs + 32-bit lane offset); NR rows per trip, so
+// SQ_Q * NR independent coalesced 1 KB row segments per wave are in flight.  The sum of a feature runs
+// over the rows in order whatever SQ_Q / NR are.
+template <int SQ_Q, int NR>
+DEV void gm_sq_core(gptr_cc G, lptr_d lvec, lptr_i lused, const GmWork &W, int K, int M, int mode, double beta, double c1,
+                    double c2, const double *newrow, int f0, int f1, int tid, int nthr)
 {
+    typedef double d2 __attribute__((ext_vector_type(2), aligned(8)));   // rows of an odd-K matrix start 8 bytes off
+    typedef const d2 __attribute__((address_space(1))) *gptr_cd2;
+    for (int ib = f0; ib < f1; ib += 2 * SQ_Q * nthr) {
+        d2 accq[SQ_Q];
+        unsigned off[SQ_Q];
+#pragma unroll
+        for (int q = 0; q < SQ_Q; q++) {
+            accq[q] = d2{0, 0};
+            const int i = ib + 2 * (q * nthr + tid);
+            off[q] = (unsigned)((i < f1 ? i : f1 - 2) * 8);
+        }
+        int j = 0;
+        for (; j + NR - 1 < M; j += NR) {
+            d2 g[NR][SQ_Q];
+            double v[NR];
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                const gptr_cc row = G + (size_t)uni(lused[j + r]) * (size_t)K * 8;
+                v[r] = lvec[j + r];
+#pragma unroll
+                for (int q = 0; q < SQ_Q; q++) g[r][q] = *(gptr_cd2)(row + off[q]);
+            }
+#pragma unroll
+            for (int r = 0; r < NR; r++)
+#pragma unroll
+                for (int q = 0; q < SQ_Q; q++) accq[q] += g[r][q] * v[r];
+        }
+        for (; j < M; j++) {
+            const gptr_cc row = G + (size_t)uni(lused[j]) * (size_t)K * 8;
+            const double v0 = lvec[j];
+#pragma unroll
+            for (int q = 0; q < SQ_Q; q++) accq[q] += *(gptr_cd2)(row + off[q]) * v0;
+        }
+#pragma unroll
+        for (int q = 0; q < SQ_Q; q++) {
+            const int i = ib + 2 * (q * nthr + tid);
+            if (i < f1) {
+                gm_sq_apply(W, mode, beta, c1, c2, newrow, i, accq[q][0]);
+                gm_sq_apply(W, mode, beta, c1, c2, newrow, i + 1, accq[q][1]);
+            }
+        }
+    }
+}
+// stage row ids and the vector in LDS, then tiles [t0, t1) of 128 features with one pair per thread
+// (the shape a claimed chunk has: owner and helpers)
+DEV void gm_sq_tiles(const Blk &B, const FoldDev &F, const GmWork &W, int K, int M, const double *vec, int mode, double beta,
+                     double c1, double c2, const double *newrow, int t0, int t1, bool stage)
+{
+    const gptr_cc G = (gptr_cc)as_global(uni_ptr(F.G));
+    const lptr_d lvec = as_lds(B.pool);
+    const lptr_i lused = as_lds((int *)(B.pool + ((M + 1) & ~1)));
+    const int tid = B.tid, nthr = uni(B.nthr);
+    if (stage) {
+        blk_sync(B);
+        for (int j = tid; j < M; j += nthr) { lvec[j] = vec[j]; lused[j] = W.rowid[j]; }
+        blk_sync(B);
+    }
+    const int Kp = K & ~1, f0 = t0 * FS_FT, f1 = t1 * FS_FT < Kp ? t1 * FS_FT : Kp;
+    gm_sq_core<1, 8>(G, lvec, lused, W, uni(K), uni(M), mode, beta, c1, c2, newrow, f0, f1, tid, nthr);
+}
+#endif
+
+// a[i] = sum_j G[used[j], i] * vec[j] for all features, fused with the S_in/Q_in update that
+// consumes it.  `rid`: Gram row id of the new feature (mode 1), else -1.
+DEVNI void gm_sq_update(const Blk &B, const FoldDev &F, const GmWork &W, int K, int M, const double *vec,
+                        int mode, double beta, double c1, double c2, int rid, GmScalars &S)
+{
+    const double *newrow = rid >= 0 ? F.G + (size_t)rid * K : nullptr;
 #ifdef PAREBEN_HOST_EMUL
+    (void)S;
     PAR(i, K) {
         double a = 0;
         for (int j = 0; j < M; j++) a += F.G[(size_t)W.rowid[j] * K + i] * vec[j];
         gm_sq_apply(W, mode, beta, c1, c2, newrow, i, a);
     }
 #else
-    // K x M mat-vec over Gram rows: row ids / `vec` staged in LDS; every thread owns SQ_Q PAIRS of
-    // adjacent features and fetches each pair with one 16-byte load (row base in SGPRs + 32-bit lane
-    // offset), so SQ_Q independent coalesced 1 KB row segments per wave are in flight per active row.
-    constexpr int SQ_Q = 5;
-    typedef double d2 __attribute__((ext_vector_type(2), aligned(8)));   // rows of an odd-K matrix start 8 bytes off
-    typedef const d2 __attribute__((address_space(1))) *gptr_cd2;
     const gptr_cc G = (gptr_cc)as_global(uni_ptr(F.G));
     const lptr_d lvec = as_lds(B.pool);
     const lptr_i lused = as_lds((int *)(B.pool + ((M + 1) & ~1)));
@@ -627,41 +709,11 @@ DEVNI void gm_sq_update(const Blk &B, const FoldDev &F, const GmWork &W, int K, 
     for (int j = tid; j < M; j += nthr) { lvec[j] = vec[j]; lused[j] = W.rowid[j]; }
     blk_sync(B);
     const int Kp = K & ~1;                                    // pairs cover [0, Kp); an odd last feature is handled below
-    for (int ib = 0; ib < Kp; ib += 2 * SQ_Q * nthr) {
-        d2 accq[SQ_Q];
-        unsigned off[SQ_Q];
-#pragma unroll
-        for (int q = 0; q < SQ_Q; q++) {
-            accq[q] = d2{0, 0};
-            const int i = ib + 2 * (q * nthr + tid);
-            off[q] = (unsigned)((i < Kp ? i : Kp - 2) * 8);
-        }
-        int j = 0;
-        for (; j + 1 < M; j += 2) {                            // two rows per trip: 2 SQ_Q loads in flight per thread
-            const gptr_cc row0 = G + (size_t)uni(lused[j]) * (size_t)K * 8;
-            const gptr_cc row1 = G + (size_t)uni(lused[j + 1]) * (size_t)K * 8;
-            const double v0 = lvec[j], v1 = lvec[j + 1];
-            d2 g0[SQ_Q], g1[SQ_Q];
-#pragma unroll
-            for (int q = 0; q < SQ_Q; q++) { g0[q] = *(gptr_cd2)(row0 + off[q]); g1[q] = *(gptr_cd2)(row1 + off[q]); }
-#pragma unroll
-            for (int q = 0; q < SQ_Q; q++) { accq[q] += g0[q] * v0; accq[q] += g1[q] * v1; }
-        }
-        if (j < M) {
-            const gptr_cc row0 = G + (size_t)uni(lused[j]) * (size_t)K * 8;
-            const double v0 = lvec[j];
-#pragma unroll
-            for (int q = 0; q < SQ_Q; q++) accq[q] += *(gptr_cd2)(row0 + off[q]) * v0;
-        }
-#pragma unroll
-        for (int q = 0; q < SQ_Q; q++) {
-            const int i = ib + 2 * (q * nthr + tid);
-            if (i < Kp) {
-                gm_sq_apply(W, mode, beta, c1, c2, newrow, i, accq[q][0]);
-                gm_sq_apply(W, mode, beta, c1, c2, newrow, i + 1, accq[q][1]);
-            }
-        }
-    }
+    const int n_tiles = (Kp + FS_FT - 1) / FS_FT;
+    const bool shared = M >= 96 && job_share(B, S, JOB_SQ, M, n_tiles, beta, mode, rid, c1, c2, [&](int t0, int t1) {
+        gm_sq_tiles(B, F, W, K, M, vec, mode, beta, c1, c2, newrow, t0, t1, false);
+    });
+    if (!shared) gm_sq_core<5, 2>(G, lvec, lused, W, K, M, mode, beta, c1, c2, newrow, 0, Kp, tid, nthr);
     if ((K & 1) && tid == 0) {                                // the odd last feature
         double a = 0;
         for (int j = 0; j < M; j++) a += *(gptr_cd)(G + ((size_t)lused[j] * (size_t)K + (K - 1)) * 8) * lvec[j];
@@ -688,7 +740,7 @@ DEVNI void gm_reestimate(const Blk &B, const FoldDev &F, const GmWork &W, int K,
         const double f = kappa * W.v2[j];
         for (int i = B.lane; i < M; i += BLK_LANES) W.Sig[(size_t)j * ld + i] -= f * W.v2[i];
     }
-    gm_sq_update(B, F, W, K, M, W.v2, 0, S.beta, kappa, mujj, nullptr);
+    gm_sq_update(B, F, W, K, M, W.v2, 0, S.beta, kappa, mujj, -1, S);
 }
 
 // Gram row of feature u = the reference's BASIS_PHI row for that basis (MainEff.c:1608-1630):
@@ -823,7 +875,7 @@ DEVNI void gm_add(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScal
         W.rowid[M] = rid;
         W.upos[nu] = M;
     }
-    gm_sq_update(B, F, W, K, M, W.v2, 1, beta, sii, mui, row);
+    gm_sq_update(B, F, W, K, M, W.v2, 1, beta, sii, mui, rid, S);
     GM_TRACE("    add nu=%d newA=%.15g sii=%.15g mui=%.15g tp0=%.15g tmp0=%.15g Sin=%.15g Qin=%.15g mu0=%.15g\n", nu, newA, sii, mui, W.v2[0], W.v1[0], W.Sin[nu], W.Qin[nu], W.mu[0]);
     S.M = M + 1;
 }
@@ -839,7 +891,7 @@ DEVNI void gm_delete(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmS
     const int mujj = (int)W.mu[jj];                           // Q2: int truncation
     const int gone = W.used[jj];
     const int gone_row = W.rowid[jj];
-    gm_sq_update(B, F, W, K, M, W.v2, 2, S.beta, sjj, (double)mujj, nullptr);
+    gm_sq_update(B, F, W, K, M, W.v2, 2, S.beta, sjj, (double)mujj, -1, S);
     PAR(i, M) W.mu[i] = W.mu[i] - mujj * W.v2[i] / sjj;
     for (int j = B.wave; j < M; j += B.nwave) {
         const double vj = W.v2[j];

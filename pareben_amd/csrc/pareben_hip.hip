@@ -342,6 +342,7 @@ __device__ void fs_help_loop(const Blk &B, const FsShare &sh, int K)
                 const int b = base + B.lane;
                 unsigned long long w = b < sh.n_blocks ? AT_LOAD(&sh.jobs[b].word) : 0ull;
                 const int nt = (b < sh.n_blocks && fs_epoch_open(w)) ? AT_LOAD(&sh.jobs[b].n_tiles) : 0;
+                const int chunk = (b < sh.n_blocks && fs_epoch_open(w)) ? job_chunk(AT_LOAD(&sh.jobs[b].kind)) : FS_CHUNK;
                 unsigned long long cand = __ballot(fs_epoch_open(w) && (int)(unsigned)w < nt);
                 while (cand && owner < 0) {
                     const int l = __ffsll((long long)cand) - 1;
@@ -349,7 +350,7 @@ __device__ void fs_help_loop(const Blk &B, const FsShare &sh, int K)
                     int got = -1;
                     if (B.lane == l) {
                         unsigned long long e = w;
-                        if (__hip_atomic_compare_exchange_strong(&sh.jobs[b].word, &e, w + FS_CHUNK, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                        if (__hip_atomic_compare_exchange_strong(&sh.jobs[b].word, &e, w + chunk, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
                                                                  __HIP_MEMORY_SCOPE_AGENT)) got = (int)(unsigned)w;
                     }
                     got = __shfl(got, l, 64);
@@ -369,10 +370,17 @@ __device__ void fs_help_loop(const Blk &B, const FsShare &sh, int K)
         __syncthreads();
         FsJob *job = sh.jobs + owner;
         const int M = AT_LOAD(&job->M), fold = AT_LOAD(&job->fold), n_tiles = AT_LOAD(&job->n_tiles);
+        const int kind = AT_LOAD(&job->kind), mode = AT_LOAD(&job->mode), rid = AT_LOAD(&job->rid);
         const double beta = __hip_atomic_load(&job->beta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double c1 = __hip_atomic_load(&job->c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double c2 = __hip_atomic_load(&job->c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const GmWork Wo = ws_carve(sh.ws + (size_t)owner * sh.ws_stride, K, sh.cap, sh.offK, sh.offSig, sh.offM);
         const FoldDev Fo = sh.folds[fold];
-        gm_fullstat_features(B, Fo, Wo, K, M, beta, first, first + FS_CHUNK < n_tiles ? first + FS_CHUNK : n_tiles);
+        const int last = first + job_chunk(kind) < n_tiles ? first + job_chunk(kind) : n_tiles;
+        if (kind == JOB_SQ)
+            gm_sq_tiles(B, Fo, Wo, K, M, Wo.v2, mode, beta, c1, c2, rid >= 0 ? Fo.G + (size_t)rid * K : nullptr, first, last, true);
+        else
+            gm_fullstat_features(B, Fo, Wo, K, M, beta, first, last);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // every wave drains its S_in / Q_in stores
         __syncthreads();
         if (threadIdx.x == 0) {

@@ -65,17 +65,18 @@ struct GmWork {
     int cap, ld;
 };
 
-// One full-stat pass offered to idle workgroups (gm_fit.h, "shared full-stat passes").  `word` packs
+// One feature-parallel phase of a fit offered to idle workgroups (gm_fit.h, "shared phases").  `word` packs
 // (epoch << 32) | next_tile: odd epoch = open; tiles are claimed by compare-and-swap on the whole word,
 // so a claim always belongs to the pass that was open when it was made.
 struct FsJob {
     unsigned long long word;
     int done;              // chunks finished (by anyone)
-    int fold, M, n_tiles;
-    int pad[2];
-    double beta;
-    double pad2[3];        // one 64-byte line per job
+    int fold, M, n_tiles;  // n_tiles: 128-feature tiles of the K features
+    int kind, mode, rid;   // JOB_FULLSTAT | JOB_SQ; for JOB_SQ the update mode and the new feature's Gram row id
+    int pad;
+    double beta, c1, c2;   // one 64-byte line per job
 };
+enum { JOB_FULLSTAT = 0, JOB_SQ = 1 };
 struct FsShare {           // null jobs = sharing off
     FsJob *jobs;           // one per workgroup of the launch
     int *active;           // workgroups that still own a fit or may pull one from the queue
