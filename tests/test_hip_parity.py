@@ -257,3 +257,27 @@ def test_lazy_gram_rows_epistasis(golden, monkeypatch):
     assert np.array_equal(stl, stf)
     ok = (stl & 8) == 0
     assert _rel(El[ok], Ef[ok]).max() < 1e-8
+
+
+def test_shared_phases_bit_identical(oracle, monkeypatch):
+    """Fewer fits than workgroups: the queue is drained at once, so every full-stat pass and action
+    mat-vec of the running fits is opened to ~200 idle workgroups (job board, CAS claims, agent-scope
+    hand-offs).  Scores, status and counters must be bit-identical to the run with sharing off."""
+    X, y = synthetic_gaussian(500, 4500, n_causal=25, seed=4242)
+    fid = AssignToFolds(X, 3)
+    alpha, lam = BuildGrid(X, y, 3)
+    sel = np.array([45, 130, 135, 190, 250, 255, 310, 375, 399])        # around and below the sparse-to-dense transition
+    out = {}
+    for share in ("0", "1"):
+        monkeypatch.setenv("PAREBEN_SHARE", share)
+        with pareben_amd.Context(X, y, fid, 3) as ctx:
+            out[share] = ctx.run(alpha[sel], lam[sel])
+            if share == "1":
+                again = ctx.run(alpha[sel][::-1], lam[sel][::-1])
+    E0, st0, c0 = out["0"]
+    E1, st1, c1 = out["1"]
+    assert np.all(st1 & 8 == 0) and c1[..., 10].max() >= 96             # active sets large enough to open both job kinds
+    assert np.array_equal(E0, E1) and np.array_equal(st0, st1) and np.array_equal(c0[..., :11], c1[..., :11])
+    assert np.array_equal(again[0][::-1], E1)
+    Eo, _, rc = oracle.cv_grid(X, y, fid, 3, alpha[sel][:2], lam[sel][:2], n_threads=6)
+    assert rc == 0 and _rel(E1[:2], Eo).max() < 1e-8
