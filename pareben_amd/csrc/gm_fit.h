@@ -405,7 +405,7 @@ DEV bool job_share(const Blk &B, GmScalars &S, int kind, int M, int n_tiles, dou
     const int chunk = job_chunk(kind);
     if (!(sh && sh->jobs) || n_tiles < 4 * chunk) return false;
     __syncthreads();
-    if (B.tid == 0) B.ired[0] = AT_LOAD(sh->queue) >= sh->n_units;         // queue drained: others are idle
+    if (B.tid == 0) B.ired[0] = sh->early || AT_LOAD(sh->queue) >= sh->n_units;   // somebody may be free to help
     __syncthreads();
     const bool open = B.ired[0] != 0;
     __syncthreads();

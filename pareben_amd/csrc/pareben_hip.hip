@@ -291,8 +291,9 @@ struct CvParams {
     size_t ws_stride, offK, offSig, offM;
     int K, cap, n_folds, n_units;
     int priv_base0, priv_rows;         // lazy Gram mode: private rows of workgroup b start at priv_base0 + b * priv_rows
-    FsJob *jobs;                       // shared full-stat passes (gm_fit.h); null = off
+    FsJob *jobs;                       // shared phases (gm_fit.h); null = off
     int *active;
+    int early;                         // share from the start (few fits per workgroup)
     GmVariant v;
 };
 
@@ -327,17 +328,19 @@ __device__ inline void store_counters(long long *dst, const FitCounters &c)
 // A workgroup that found the work queue empty helps the fits still running: it scans the job board (64
 // owners per load with wave 0), claims a chunk of feature tiles of an open full-stat pass and runs it on
 // the owner's state (gm_fit.h, "shared full-stat passes").  Leaves when no workgroup owns a fit any more.
-__device__ void fs_help_loop(const Blk &B, const FsShare &sh, int K)
+// `until_all_done`: the tail of the launch (this workgroup owns nothing any more: stay until no workgroup
+// owns a fit).  Otherwise: between two fits, help as long as some open job has chunks left, then return.
+__device__ void fs_help_loop(const Blk &B, const FsShare &sh, int K, bool until_all_done)
 {
     __shared__ int s_pick[4];
     if (!sh.jobs) return;
     __syncthreads();
-    if (threadIdx.x == 0) AT_ADD(sh.active, -1);
+    if (until_all_done && threadIdx.x == 0) AT_ADD(sh.active, -1);
     for (;;) {
         __syncthreads();
         if (B.wave == 0) {
             int owner = -1, first = -1;
-            const int quit = AT_LOAD(sh.active) <= 0;
+            const int quit = until_all_done && AT_LOAD(sh.active) <= 0;
             for (int base = 0; !quit && owner < 0 && base < sh.n_blocks; base += 64) {
                 const int b = base + B.lane;
                 unsigned long long w = b < sh.n_blocks ? AT_LOAD(&sh.jobs[b].word) : 0ull;
@@ -362,7 +365,11 @@ __device__ void fs_help_loop(const Blk &B, const FsShare &sh, int K)
         __syncthreads();
         const int owner = s_pick[0], first = s_pick[1], quit = s_pick[2];
         if (quit) break;
-        if (owner < 0) { __builtin_amdgcn_s_sleep(127); continue; }
+        if (owner < 0) {
+            if (!until_all_done) break;
+            __builtin_amdgcn_s_sleep(127);
+            continue;
+        }
         if (threadIdx.x == 0) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");       // the owner's Sigma, mu, row ids, bt
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -403,8 +410,9 @@ __global__ __launch_bounds__(FIT_THREADS) void gm_cv_kernel(CvParams P)
     FsShare sh;
     sh.jobs = P.jobs; sh.active = P.active; sh.queue = P.queue; sh.n_units = P.n_units; sh.n_blocks = gridDim.x;
     sh.self = blockIdx.x; sh.ws = P.ws; sh.ws_stride = P.ws_stride; sh.offK = P.offK; sh.offSig = P.offSig; sh.offM = P.offM;
-    sh.folds = P.folds; sh.cap = P.cap;
-    for (;;) {
+    sh.folds = P.folds; sh.cap = P.cap; sh.early = P.early;
+    for (int n_done = 0;; n_done++) {
+        if (P.early && n_done > 0) fs_help_loop(B, sh, P.K, false);   // between fits: lend a hand to the long ones
         __syncthreads();
         if (threadIdx.x == 0) s_unit = atomicAdd(P.queue, 1);
         __syncthreads();
@@ -438,7 +446,7 @@ __global__ __launch_bounds__(FIT_THREADS) void gm_cv_kernel(CvParams P)
             if (P.counters) store_counters(P.counters + (size_t)unit * PAREBEN_NCOUNTERS, s_cnt);
         }
     }
-    fs_help_loop(B, sh, P.K);
+    fs_help_loop(B, sh, P.K, true);
 }
 
 struct BmCvParams {
@@ -895,8 +903,10 @@ extern "C" int pareben_ctx_run(pareben_ctx *c, int n_cells, const double *alpha,
     CK(hipMemcpyAsync(d_lambda, lambda, sizeof(double) * n_cells, hipMemcpyHostToDevice, c->stream));
     CK(hipMemcpyAsync(d_order, order.data(), sizeof(int) * n_units, hipMemcpyHostToDevice, c->stream));
     CK(hipMemsetAsync(d_queue, 0, sizeof(int), c->stream));
-    const char *share_env = getenv("PAREBEN_SHARE");            // PAREBEN_SHARE=0: no shared full-stat passes (A/B tests)
-    if (!binom && !(share_env && share_env[0] == '0')) {
+    // PAREBEN_SHARE (A/B tests): 0 = no shared phases, 1 = in the tail only, 2 = from the start; unset = automatic
+    const char *share_env = getenv("PAREBEN_SHARE");
+    const int share_mode = share_env ? atoi(share_env) : -1;
+    if (!binom && share_mode != 0) {
         CK(dmalloc(&d_jobs, (size_t)blocks)); CK(dmalloc(&d_active, (size_t)4));
         CK(hipMemsetAsync(d_jobs, 0, sizeof(FsJob) * (size_t)blocks, c->stream));
         act_host[0] = blocks;
@@ -917,6 +927,9 @@ extern "C" int pareben_ctx_run(pareben_ctx *c, int n_cells, const double *alpha,
     P.K = c->kfull; P.cap = c->cap; P.n_folds = nF; P.n_units = n_units; P.v = c->variant;
     P.priv_rows = c->priv_rows; P.priv_base0 = nF * c->pool_rows;
     P.jobs = d_jobs; P.active = d_active;
+    // with only a handful of fits per workgroup the longest fits decide the step time: share from the start
+    // (measured on config-2 shares: 1250 fits 2.59 -> 2.49 s; with 2500 or more fits it costs more than it gains)
+    P.early = (d_jobs && (share_mode == 2 || (share_mode < 0 && n_units < 6 * blocks))) ? 1 : 0;
     if (binom) {
         BmCvParams Q;
         Q.folds = c->d_folds; Q.alpha = d_alpha; Q.lambda = d_lambda; Q.order = d_order; Q.queue = d_queue;

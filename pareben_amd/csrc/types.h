@@ -86,4 +86,5 @@ struct FsShare {           // null jobs = sharing off
     size_t ws_stride, offK, offSig, offM;
     const FoldDev *folds;
     int cap;
+    int early;             // few fits per workgroup: phases are shared from the start, not only once the queue is drained
 };

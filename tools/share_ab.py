@@ -14,12 +14,12 @@ alpha, lam = BuildGrid(X, y, 5, nAlpha=20, nLambda=100)
 fid = AssignToFolds(X, 5)
 mine = shard_cells(alpha, lam, 0, world)
 res = {}
-for share in ("0", "1"):
+for share in ("0", "1", "2"):
     os.environ["PAREBEN_SHARE"] = share
     with pareben_amd.Context(X, y, fid, 5) as ctx:
         E, st, cnt = ctx.run(alpha[mine], lam[mine])
         res[share] = (E, st, cnt, ctx.last_timing())
     print("share", share, "fits", E.size, res[share][3], flush=True)
-same = np.array_equal(res["0"][0], res["1"][0], equal_nan=True) and np.array_equal(res["0"][1], res["1"][1]) and np.array_equal(res["0"][2][..., :11], res["1"][2][..., :11])
-print("bit-identical:", same, "aborted:", int(((res["1"][1] & 8) != 0).sum()))
+same = all(np.array_equal(res["0"][0], res[k][0], equal_nan=True) and np.array_equal(res["0"][1], res[k][1]) and np.array_equal(res["0"][2][..., :11], res[k][2][..., :11]) for k in ("1", "2"))
+print("bit-identical:", same, "aborted:", int(((res["2"][1] & 8) != 0).sum()))
 sys.exit(0 if same else 1)
