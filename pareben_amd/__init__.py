@@ -1,14 +1,15 @@
 """pareben_amd -- MI355X-native cross-validation hot path of parEBEN.
 
 Public surface (mirrors the reference's R names):
-  CrossValidate, BuildGrid, GetLambdaMax, AssignToFolds   (host side, R/*.R)
+  CrossValidate, LocalSearch, BuildGrid, GetLambdaMax, AssignToFolds   (host side, R/*.R)
   EBelasticNet.Gaussian / EBelasticNet.Binomial           (refit at the optimum, EBEN_orig/R/*.R)
   Context, fit_gaussian, fit_binomial                      (thin wrappers over the C ABI)
 """
 from .grid import BuildGrid, GetLambdaMax, AssignToFolds, summarise_cv
 from .cv import CrossValidate
+from .local import LocalSearch
 from ._lib import Context, fit_gaussian, fit_binomial, ParebenError, load as load_library
 from .eben import EBelasticNet, pt
 
-__all__ = ["CrossValidate", "BuildGrid", "GetLambdaMax", "AssignToFolds", "summarise_cv",
+__all__ = ["CrossValidate", "LocalSearch", "BuildGrid", "GetLambdaMax", "AssignToFolds", "summarise_cv",
            "Context", "fit_gaussian", "fit_binomial", "EBelasticNet", "pt", "ParebenError", "load_library"]

@@ -33,9 +33,9 @@ def CrossValidate(BASIS, Target, nFolds, foldId=0, Epis="no", prior="gaussian", 
     device, sample_kind (R's sampler generation for the folds), and rank/world_size/gather for the
     one-process-per-GPU split of the grid (see pareben_amd.dist).
     """
-    if search != "global":
-        raise NotImplementedError('search="local" is sequential in (alpha, lambda) by construction '
-                                  "(R/LocalSearch.R:56-115) and is not part of the accelerated path")
+    if search != "global":                  # R/CrossValidate.R:112-115
+        from .local import LocalSearch
+        return LocalSearch(BASIS, Target, nFolds, Epis, foldId, prior, device=device, sample_kind=sample_kind)
     if prior not in ("gaussian", "binomial"):
         raise ValueError('prior must be "gaussian" or "binomial"')
     X = np.asarray(BASIS, dtype=np.float64)
