@@ -20,7 +20,6 @@ struct Blk {
     double *red;     // reduction scratch (unused on the host)
     int *ired;
     double *pool;    // phase-local LDS pool (device only)
-    double *xred;
     int pool_n;
 };
 DEV void blk_sync(const Blk &) {}
@@ -41,7 +40,6 @@ struct Blk {
     double *red;     // LDS: >= 2*BLK_MAX_WAVES doubles
     int *ired;       // LDS: >= 2*BLK_MAX_WAVES ints
     double *pool;    // LDS: pool_n doubles, owned by whichever phase is running
-    double *xred;    // LDS: 2*BLK_MAX_WAVES*64 doubles
     int pool_n;
 };
 DEV void blk_sync(const Blk &) { __syncthreads(); }

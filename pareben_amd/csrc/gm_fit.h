@@ -25,11 +25,7 @@
 #pragma once
 #include "blk.h"
 #include "types.h"
-#ifdef PAREBEN_HOST_EMUL
-#define FS_FT_OR_ONE 128
-#else
-#define FS_FT_OR_ONE FS_FT
-#endif
+
 #if defined(PAREBEN_HOST_EMUL) && defined(PAREBEN_TRACE)
 #include <stdio.h>
 #define GM_TRACE(...) fprintf(stderr, __VA_ARGS__)
@@ -455,8 +451,10 @@ DEV bool job_share(const Blk &B, GmScalars &S, int kind, int M, int n_tiles, dou
 
 DEVNI void gm_fullstat_pass(const Blk &B, const FoldDev &F, const GmWork &W, int K, int M, double beta, GmScalars &S)
 {
-    const int n_tiles = (K + FS_FT_OR_ONE - 1) / FS_FT_OR_ONE;
-#ifndef PAREBEN_HOST_EMUL
+#ifdef PAREBEN_HOST_EMUL
+    const int n_tiles = 1;                                    // the host build has no tiles: one call does all features
+#else
+    const int n_tiles = (K + FS_FT - 1) / FS_FT;
     if (M >= 48 && job_share(B, S, JOB_FULLSTAT, M, n_tiles, beta, 0, -1, 0.0, 0.0,
                              [&](int t0, int t1) { gm_fullstat_features(B, F, W, K, M, beta, t0, t1); })) return;
 #endif

@@ -298,10 +298,9 @@ struct CvParams {
 };
 
 // LDS carve of one fit workgroup (dynamic shared memory): a phase-local pool (full-stat Gram
-// tiles / inverse panels / action vectors), the cross-wave reduction slab and the small scratch.
+// k-blocks and Sigma panels / inverse panels / action vectors) and the small reduction scratch.
 #define LDS_POOL_DOUBLES 16384
-#define LDS_XRED_DOUBLES (2 * BLK_MAX_WAVES * 64)
-#define LDS_FIT_BYTES ((LDS_POOL_DOUBLES + LDS_XRED_DOUBLES + 2 * BLK_MAX_WAVES) * 8 + 2 * BLK_MAX_WAVES * 4)
+#define LDS_FIT_BYTES ((LDS_POOL_DOUBLES + 2 * BLK_MAX_WAVES) * 8 + 2 * BLK_MAX_WAVES * 4)
 extern __shared__ double lds_dyn[];
 
 __device__ inline Blk make_blk()
@@ -312,8 +311,7 @@ __device__ inline Blk make_blk()
     B.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     B.nwave = blockDim.x >> 6;
     B.pool = lds_dyn; B.pool_n = LDS_POOL_DOUBLES;
-    B.xred = lds_dyn + LDS_POOL_DOUBLES;
-    B.red = B.xred + LDS_XRED_DOUBLES;
+    B.red = lds_dyn + LDS_POOL_DOUBLES;
     B.ired = (int *)(B.red + 2 * BLK_MAX_WAVES);
     return B;
 }

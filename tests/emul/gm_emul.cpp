@@ -122,7 +122,7 @@ static int emul_gauss_grid(const double *basis_in, int n, int p_in, const double
     for (int f = 0; f < n_folds; f++) prepare(folds[f], basis, n, p, y, fold_id, f);
     Work ws(p, cap);
     int ired[4];
-    Blk B; B.tid = 0; B.nthr = 1; B.lane = 0; B.wave = 0; B.nwave = 1; B.red = nullptr; B.ired = ired; B.pool = nullptr; B.xred = nullptr; B.pool_n = 0;
+    Blk B; B.tid = 0; B.nthr = 1; B.lane = 0; B.wave = 0; B.nwave = 1; B.red = nullptr; B.ired = ired; B.pool = nullptr; B.pool_n = 0;
     // PAREBEN_EMUL_LAZY=<rows per fold>[,<private rows>]: exercise the on-demand Gram-row pool (and the
     // per-workgroup private rows behind it) instead of the full matrix
     const char *lz = getenv("PAREBEN_EMUL_LAZY");
@@ -174,7 +174,7 @@ extern "C" int emul_gm_fit(const double *X, const double *y, int n, int p, doubl
     Fold F; prepare(F, X, n, p, y, fid.data(), 0);
     const int cap = emul_default_cap(p);
     Work ws(p, cap);
-    Blk B; B.tid = 0; B.nthr = 1; B.lane = 0; B.wave = 0; B.nwave = 1; B.red = nullptr; B.ired = nullptr; B.pool = nullptr; B.xred = nullptr; B.pool_n = 0;
+    Blk B; B.tid = 0; B.nthr = 1; B.lane = 0; B.wave = 0; B.nwave = 1; B.red = nullptr; B.ired = nullptr; B.pool = nullptr; B.pool_n = 0;
     FoldDev D = dev_view(F);
     GmScalars S; FitCounters cnt; S.c = &cnt; S.ph = nullptr; S.v = GmVariant{0, 0.9, 0.001, 1e-3, 1e2, 1e-10};
     gm_fit(B, D, ws.W, p, lambda, alpha, S);
@@ -208,7 +208,7 @@ extern "C" int emul_bm_cv_grid(const double *basis, int n, int p, const double *
     d = nd.data();
     W.w = d; d += nmax; W.pm = d; d += nmax; W.yv = d; d += nmax; W.e = d; d += nmax; W.bphi = d;
     W.BP = bp.data(); W.cap = cap; W.ld = ld;
-    Blk B; B.tid = 0; B.nthr = 1; B.lane = 0; B.wave = 0; B.nwave = 1; B.red = nullptr; B.ired = nullptr; B.pool = nullptr; B.xred = nullptr; B.pool_n = 0;
+    Blk B; B.tid = 0; B.nthr = 1; B.lane = 0; B.wave = 0; B.nwave = 1; B.red = nullptr; B.ired = nullptr; B.pool = nullptr; B.pool_n = 0;
     for (int c = 0; c < n_cells; c++)
         for (int f = 0; f < n_folds; f++) {
             FoldDev F = dev_view(folds[f]);
