@@ -38,7 +38,7 @@ def replay_local_search(alpha_desc, lam_desc, fold_err_of):
         for il, lam in enumerate(lam_desc):
             # which.min(SSE1Alpha[1:(i_s-1), 1]): for the first step R's 1:0 = c(1, 0) selects row 1 (still 1e10)
             upto = il if il >= 1 else 1
-            mi = int(np.argmin(sse[:upto, 0]))
+            mi = int(np.nanargmin(sse[:upto, 0]))              # which.min skips NA (a flagged fit scores NaN)
             previous = sse[mi, 0] + sse[mi, 1]
             e = np.asarray(fold_err_of(ia, il), dtype=np.float64)
             mean, se = float(np.mean(e)), r_sd(e) / math.sqrt(len(e))
@@ -48,9 +48,9 @@ def replay_local_search(alpha_desc, lam_desc, fold_err_of):
             step += 1
             if mean - previous > 0:                              # early stop for this alpha
                 break
-        idx = int(np.argmin(sse[:, 0]))
+        idx = int(np.nanargmin(sse[:, 0]))
         each[ia] = (a, lam_desc[idx], sse[idx, 0], sse[idx, 1])
-    best = int(np.argmin(each[:, 2]))
+    best = int(np.nanargmin(each[:, 2]))
     return each, float(each[best, 0]), float(each[best, 1]), msecv, visited
 
 

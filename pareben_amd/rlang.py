@@ -85,14 +85,15 @@ class RRandom:
             if dv < dn:
                 return dv
 
-    def sample(self, x):
-        """``sample(x, length(x))``: a random permutation of x (R's do_sample, no replacement)."""
+    def sample(self, x, size=None):
+        """``sample(x, size)`` without replacement (R's do_sample); default size = length(x): a random
+        permutation.  The first `size` picks do not depend on `size`."""
         x = list(x)
         n = len(x)
         idx = list(range(n))
         out = []
         m = n
-        for _ in range(n):
+        for _ in range(n if size is None else int(size)):
             j = int(self.unif_index(m))
             out.append(x[idx[j]])
             m -= 1

@@ -281,3 +281,31 @@ def test_shared_phases_bit_identical(oracle, monkeypatch):
     assert np.array_equal(again[0][::-1], E1)
     Eo, _, rc = oracle.cv_grid(X, y, fid, 3, alpha[sel][:2], lam[sel][:2], n_threads=6)
     assert rc == 0 and _rel(E1[:2], Eo).max() < 1e-8
+
+
+def test_paper_epistasis_dataset_vs_oracle(oracle):
+    """The Epis data set of the authors' timing script (yeast genotypes, n = 200; tools/make_golden.py):
+    its first 90 markers -> 4095 implicit columns, five cells around the sparse-to-dense transition
+    against the oracle, plus search = "local" reporting a cell of the global table (the full 300 / 600
+    marker jobs: profiles/r01/config4_paper_epis_jobs.json)."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "yeast_timing_200x600.npz"))
+    B = np.asfortranarray(np.unpackbits(d["bits"], axis=0)[:200].astype(np.float64) * 2.0 - 1.0)
+    X, y = np.asfortranarray(B[:, :90]), d["y"].astype(np.float64)
+    glo = pareben_amd.CrossValidate(X, y, nFolds=5, Epis="yes", prior="gaussian", search="global", return_stats=True)
+    loc = pareben_amd.CrossValidate(X, y, nFolds=5, Epis="yes", prior="gaussian", search="local")
+    ok = (glo["stats"]["status"] & 8 == 0).all(axis=1)         # the smallest lambdas run into M >= N (non-SPD Hessian): flagged
+    assert ok.mean() > 0.7
+    alpha, lam = BuildGrid(X, y, 5, "yes")
+    # the early-stopping walk need not find the global optimum; what it reports is a cell of the same table
+    S = glo["Results.Summary"]
+    j = np.nonzero((np.asarray(S["alpha"]) == loc["alpha.optimal"]) & (np.asarray(S["lambda"]) == loc["lambda.optimal"]))[0]
+    k = int(np.argmin(loc["CrossValidation"][:, 2]))
+    assert len(j) == 1 and abs(np.asarray(S["MSE"])[j[0]] - loc["CrossValidation"][k, 2]) < 1e-9 * loc["CrossValidation"][k, 2]
+    fid = AssignToFolds(X, 5)
+    E = np.asarray(glo["Results.Detail"]["MSE"]).reshape(400, 5)
+    m = np.where(ok, glo["stats"]["counters"][..., 10].max(axis=1), -1)
+    sel = np.argsort(-m)[:5]                                   # the five complete cells with the largest active sets
+    Eo, _, rc = oracle.cv_grid(X, y, fid, 5, alpha[sel], lam[sel], epis=True, n_threads=8)
+    assert rc == 0 and m[sel].max() >= 20
+    assert _rel(E[sel], Eo).max() < 1e-6                       # active sets close to N = 160: ill-conditioned, observed <= 6e-8

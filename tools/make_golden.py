@@ -102,6 +102,29 @@ def main():
         np.savez_compressed(OUT + "/yeast_looser10000.npz", bits=np.packbits((Gy > 0).astype(np.uint8), axis=0),
                             n=np.int64(Gy.shape[0]), p=np.int64(Gy.shape[1]), pheno=ph)
 
+    # The Epis data set of the authors' timing script (paper_materials/Timing Tests/test_time_Gaus.R:13-42,
+    # n = 200, k = 600 rows of its template): genotype rows of the samples that have a phenotype, then
+    # set.seed(1); sample(1:nrow, n); sample(1:ncol, k) with the R < 3.6 sampler (the runs are from April
+    # 2018), phenotypes 1..n.  The k = 300 tests use the first 300 of these columns (the first picks of
+    # sample() do not depend on its size).  PAPER_TIMING=1 enables it (46 s to parse the 310 MB table).
+    if os.environ.get("PAPER_TIMING"):
+        import zipfile
+        import pandas as pd
+        from pareben_amd.rlang import RRandom
+        tt = REF + "/paper_materials/Timing Tests"
+        with zipfile.ZipFile(tt + "/genotype_full.zip").open("genotype_full.txt") as f:
+            df = pd.read_csv(f, sep="\t", header=0, dtype=str)
+        ph = pd.read_csv(tt + "/pheno_left.txt", sep=r"\s+", header=None)
+        keep = df.iloc[:, 0].isin(set(ph[0].values)).values
+        geno3 = df.loc[keep].iloc[:, 1:].values.astype(np.int8)            # samples x markers, +-1
+        rng = RRandom(1, sample_kind="Rounding")
+        sn = np.array(rng.sample(range(1, geno3.shape[0] + 1), 200))
+        sk = np.array(rng.sample(range(1, geno3.shape[1] + 1), 600))
+        Bt = geno3[sn - 1][:, sk - 1]
+        np.savez_compressed(OUT + "/yeast_timing_200x600.npz", bits=np.packbits((Bt > 0).astype(np.uint8), axis=0),
+                            n=np.int64(200), k=np.int64(600), y=ph[1].values[:200].astype(np.float64),
+                            sample_n=sn.astype(np.int32), sample_k=sk.astype(np.int32))
+
     # numbers recorded in SURVEY.md section 10 (compiled reference C, survey session)
     known = {
         "config1": {
