@@ -287,7 +287,7 @@ def test_paper_epistasis_dataset_vs_oracle(oracle):
     """The Epis data set of the authors' timing script (yeast genotypes, n = 200; tools/make_golden.py):
     its first 90 markers -> 4095 implicit columns, five cells around the sparse-to-dense transition
     against the oracle, plus search = "local" reporting a cell of the global table (the full 300 / 600
-    marker jobs: profiles/r01/config4_paper_epis_jobs.json)."""
+    marker jobs: profiles/r01/paper_timing_jobs.json)."""
     import os
     d = np.load(os.path.join(os.path.dirname(__file__), "golden", "yeast_timing_200x600.npz"))
     B = np.asfortranarray(np.unpackbits(d["bits"], axis=0)[:200].astype(np.float64) * 2.0 - 1.0)

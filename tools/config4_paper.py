@@ -33,5 +33,19 @@ for k in ks:
                    "kernel_ms": st["timing"], "launch": st["launch"], "aborted_fits": int(((st["status"] & 8) != 0).sum()),
                    "max_active": int(st["counters"][..., 10].max()), "paper_8_workers": paper.get(k)}
     print(json.dumps(rep[str(k)]), flush=True)
+# two main-effect rows of the authors' table (testoutput_time_4-11-2018_gaussian_cf.csv:42, :61)
+dm = np.load(os.path.join(ROOT, "tests", "golden", "yeast_timing_main.npz"))
+for (nn, kk, nf, ser, par) in ((800, 600, 7, 6182.03, 350.65), (1000, 1200, 10, 2548.08, 2280.33)):
+    if ks != [300, 600]:
+        break
+    Xm = np.asfortranarray(np.unpackbits(dm["bits_%dx%d" % (nn, kk)], axis=0)[:nn].astype(np.float64) * 2.0 - 1.0)
+    ym = dm["y"][:nn]
+    t0 = time.time()
+    loc = pareben_amd.CrossValidate(Xm, ym, nFolds=nf, Epis="no", prior="gaussian", search="local")
+    t_local = time.time() - t0
+    rep["main_%dx%d" % (nn, kk)] = {"n": nn, "k": kk, "nFolds": nf, "Epis": "no", "local_search_wall_s": t_local,
+                                    "local_alpha_opt": loc["alpha.optimal"], "local_lambda_opt": loc["lambda.optimal"],
+                                    "paper_8_workers": {"serial_elapsed_s": ser, "parallel_elapsed_s": par}}
+    print(json.dumps(rep["main_%dx%d" % (nn, kk)]), flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(rep, open(os.path.join(ROOT, "gpurun_out", "config4_paper.json"), "w"), indent=1)

@@ -124,6 +124,15 @@ def main():
         np.savez_compressed(OUT + "/yeast_timing_200x600.npz", bits=np.packbits((Bt > 0).astype(np.uint8), axis=0),
                             n=np.int64(200), k=np.int64(600), y=ph[1].values[:200].astype(np.float64),
                             sample_n=sn.astype(np.int32), sample_k=sk.astype(np.int32))
+        # two main-effect rows of the same script's table (testoutput_time_4-11-2018_gaussian_cf.csv:42, :61);
+        # the column sample depends on n (it is drawn after the n row picks), so each (n, k) is drawn afresh
+        main = {"y": ph[1].values[:1000].astype(np.float64)}
+        for (nn, kk) in ((1000, 1200), (800, 600)):
+            rng = RRandom(1, sample_kind="Rounding")
+            sn = np.array(rng.sample(range(1, geno3.shape[0] + 1), nn))
+            sk = np.array(rng.sample(range(1, geno3.shape[1] + 1), kk))
+            main["bits_%dx%d" % (nn, kk)] = np.packbits((geno3[sn - 1][:, sk - 1] > 0).astype(np.uint8), axis=0)
+        np.savez_compressed(OUT + "/yeast_timing_main.npz", **main)
 
     # numbers recorded in SURVEY.md section 10 (compiled reference C, survey session)
     known = {
