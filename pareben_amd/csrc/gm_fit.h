@@ -117,14 +117,14 @@ static_assert(16 % FS_NWAVES == 0 && FS_TPP % FS_NWAVES == 0 && FS_FT % 64 == 0,
 // a cursor names the step; what a step needs from memory is requested two steps ahead and written to
 // LDS one step ahead, across pass and tile boundaries, so memory latency is exposed once per call.
 struct FsCur { int i0, pass, h, last; };          // feature tile origin, row-tile pass, k-block, last k-block of the pass
-DEV void fs_advance(FsCur &c, int n_pass, int nJ)
+DEV void fs_advance(FsCur &c, int n_pass, int nJ, int tpp)
 {
     c.h++;
     if (c.h > c.last) {
         c.h = 0;
         c.pass++;
         if (c.pass == n_pass) { c.pass = 0; c.i0 += FS_FT; }
-        const int e = c.pass * FS_TPP + FS_TPP;
+        const int e = c.pass * tpp + tpp;
         c.last = (e < nJ ? e : nJ) - 1;
     }
 }
@@ -152,7 +152,7 @@ DEV void fs_advance(FsCur &c, int n_pass, int nJ)
 // nothing may be pending at loop entry, or the compiler puts a static vmcnt(0) inside the loop).
 template <int CUR>
 DEV void fs_step(gptr_cc Sig, gptr_cc G, lptr_i lused, lptr_d lmu, lptr_d bcur, lptr_d bnxt, lptr_d acur, lptr_d anxt,
-                 int ld, const FsCur &c0, const FsCur &c1, const FsCur &c2, int nJ, int M, int K, int wave, int lane,
+                 int ld, const FsCur &c0, const FsCur &c1, const FsCur &c2, int tpp, int nJ, int M, int K, int wave, int lane,
                  double (&pa)[2][FS_PPW][4], double (&sv)[2][FS_RPW][FS_NH], d4 (&acc)[FS_TPP], double &qsum, double &msum)
 {
     constexpr int NX = CUR ^ 1;
@@ -175,8 +175,8 @@ DEV void fs_step(gptr_cc Sig, gptr_cc G, lptr_i lused, lptr_d lmu, lptr_d bcur, 
         const unsigned lane_off = (unsigned)((l4 * ld + l15) * 8);
 #pragma unroll
         for (int pi = 0; pi < FS_PPW; pi++) {
-            const int J = c2.pass * FS_TPP + wave + pi * FS_NWAVES;
-            const bool on = J < nJ && c2.h <= J;
+            const int t2 = wave + pi * FS_NWAVES, J = c2.pass * tpp + t2;
+            const bool on = t2 < tpp && J < nJ && c2.h <= J;
             const unsigned o = on ? (unsigned)((c2.h * 16 * ld + J * 16) * 8) + lane_off : 0u;
             const unsigned st = on ? (unsigned)(4 * ld * 8) : 0u;
 #pragma unroll
@@ -184,14 +184,14 @@ DEV void fs_step(gptr_cc Sig, gptr_cc G, lptr_i lused, lptr_d lmu, lptr_d bcur, 
         }
     }
     // ---- matrix ops of step g
-    const int jb = c0.pass * FS_TPP;
+    const int jb = c0.pass * tpp;
     double bv[4];
 #pragma unroll
     for (int s = 0; s < 4; s++) bv[s] = bcur[(4 * s + l4) * FS_LD + 16 * wave + l15];
 #pragma unroll
     for (int t = 0; t < FS_TPP; t++) {
         const int J = jb + t;
-        if (J < nJ && c0.h <= J) {
+        if (t < tpp && J < nJ && c0.h <= J) {
 #pragma unroll
             for (int s = 0; s < 4; s++)
                 acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(acur[(t * 4 + s) * 64 + lane], bv[s], acc[t], 0, 0, 0);
@@ -222,13 +222,13 @@ DEV void fs_step(gptr_cc Sig, gptr_cc G, lptr_i lused, lptr_d lmu, lptr_d bcur, 
     }
 #pragma unroll
     for (int pi = 0; pi < FS_PPW; pi++) {
-        const int t = wave + pi * FS_NWAVES, J = c1.pass * FS_TPP + t;
+        const int t = wave + pi * FS_NWAVES, J = c1.pass * tpp + t;
         const double w = c1.h < J ? 2.0 : 1.0;
 #pragma unroll
         for (int s = 0; s < 4; s++) {
             double v = pa[NX][pi][s] * w;
             asm volatile("" : "+v"(v));                        // consume the load on every path (see above)
-            if (J < nJ && c1.h <= J) anxt[(t * 4 + s) * 64 + lane] = v;
+            if (t < tpp && J < nJ && c1.h <= J) anxt[(t * 4 + s) * 64 + lane] = v;
         }
     }
 }
@@ -274,19 +274,20 @@ DEVNI void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W,
     const int ld = uni(W.ld);
     const int nJ = (M + 15) >> 4;
     const int n_pass = (nJ + FS_TPP - 1) / FS_TPP;
+    const int tpp = (nJ + n_pass - 1) / n_pass;       // row tiles per pass, balanced: 19 tiles run as 10 + 9, not 16 + 3 (fewer, fuller steps)
     const int n_ft = uni(tile1) - uni(tile0);                               // feature tiles tile0 .. tile1-1 of the call
     const int i_begin = uni(tile0) * FS_FT;
     int steps_per_tile = 0;
-    for (int p = 0; p < n_pass; p++) { const int e = p * FS_TPP + FS_TPP; steps_per_tile += (e < nJ ? e : nJ); }
+    for (int p = 0; p < n_pass; p++) { const int e = p * tpp + tpp; steps_per_tile += (e < nJ ? e : nJ); }
     const int total = n_ft * steps_per_tile;
     const int l15 = lane & 15, l4 = lane >> 4;
     __syncthreads();
     for (int p = tid; p < nJ * 16; p += nthr) { lused[p < M ? p : 0] = W.rowid[p < M ? p : 0]; lmu[p] = p < M ? W.mu[p] : 0.0; }
     __syncthreads();
     FsCur c0, c1, c2;
-    c0.i0 = i_begin; c0.pass = 0; c0.h = 0; c0.last = (FS_TPP < nJ ? FS_TPP : nJ) - 1;
-    c1 = c0; fs_advance(c1, n_pass, nJ);
-    c2 = c1; fs_advance(c2, n_pass, nJ);
+    c0.i0 = i_begin; c0.pass = 0; c0.h = 0; c0.last = (tpp < nJ ? tpp : nJ) - 1;
+    c1 = c0; fs_advance(c1, n_pass, nJ, tpp);
+    c2 = c1; fs_advance(c2, n_pass, nJ, tpp);
     d4 acc[FS_TPP];
 #pragma unroll
     for (int t = 0; t < FS_TPP; t++) acc[t] = d4{0, 0, 0, 0};
@@ -311,8 +312,8 @@ DEVNI void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W,
 #pragma unroll
         for (int pi = 0; pi < FS_PPW; pi++) {
             const int t = wave + pi * FS_NWAVES;
-            const int J1 = c1.pass * FS_TPP + t;
-            const bool on0 = t < nJ, on1 = J1 < nJ && c1.h <= J1;
+            const int J1 = c1.pass * tpp + t;
+            const bool on0 = t < tpp && t < nJ, on1 = t < tpp && J1 < nJ && c1.h <= J1;
             const unsigned o0 = on0 ? (unsigned)(t * 16 * 8) + lane_off : 0u, st0 = on0 ? (unsigned)(4 * ld * 8) : 0u;
             const unsigned o1 = on1 ? (unsigned)((c1.h * 16 * ld + J1 * 16) * 8) + lane_off : 0u, st1 = on1 ? (unsigned)(4 * ld * 8) : 0u;
 #pragma unroll
@@ -340,11 +341,12 @@ DEVNI void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W,
         {                                                                                                            \
             const int cb = (gg) & 1, nb = cb ^ 1;                                                                    \
             fs_step<CURSLOT>(Sig, G, lused, lmu, lb + cb * (FS_PC * FS_LD), lb + nb * (FS_PC * FS_LD),               \
-                             la + cb * (FS_TPP * 256), la + nb * (FS_TPP * 256), ld, c0, c1, c2, nJ, M, K, wave,     \
+                             la + cb * (FS_TPP * 256), la + nb * (FS_TPP * 256), ld, c0, c1, c2, tpp, nJ, M, K,     \
+                             wave,                                                                                   \
                              lane, pa, sv, acc, qsum, msum);                                                         \
             FS_FINISH_TILE(c0)                                                                                       \
             __syncthreads();                                                                                         \
-            c0 = c1; c1 = c2; fs_advance(c2, n_pass, nJ);                                                            \
+            c0 = c1; c1 = c2; fs_advance(c2, n_pass, nJ, tpp);                                                            \
         }
     // whole pairs of steps without any skip path inside the loop (a skipped step would leave its
     // predecessor's prefetch pending on the back edge: static s_waitcnt vmcnt(0)); then the odd tail
