@@ -85,6 +85,10 @@ int pareben_ctx_create(pareben_ctx **out, int device,
  * first use (plus a few private rows per workgroup once a pool is full): same results to rounding,
  * one sweep of the fold's design per new row.  The environment variable PAREBEN_GRAM_ROWS=<rows
  * per fold>, read by pareben_ctx_create, forces that mode (diagnostics).
+ * In the tail of a launch (work queue drained) workgroups without a fit take over feature tiles of the
+ * full-stat passes and action mat-vecs of the fits still running; results are bit-identical either way.
+ * PAREBEN_SHARE=0 (read by pareben_ctx_run) turns that off, 1 keeps it to the tail, 2 shares from the
+ * start; unset = automatic (diagnostics / A-B timing).
  */
 int pareben_ctx_run(pareben_ctx *ctx, int n_cells, const double *alpha, const double *lambda,
                     double *fold_err, int32_t *status, int64_t *counters);
