@@ -333,12 +333,14 @@ __device__ void fs_help_loop(const Blk &B, const FsShare &sh, int K, bool until_
     __shared__ int s_pick[4];
     if (!sh.jobs) return;
     __syncthreads();
-    if (until_all_done && threadIdx.x == 0) AT_ADD(sh.active, -1);
     for (;;) {
         __syncthreads();
         if (B.wave == 0) {
             int owner = -1, first = -1;
-            const int quit = until_all_done && AT_LOAD(sh.active) <= 0;
+            // leave when nobody owns a fit and none is left to pull.  Leaving early is always safe: an owner only
+            // ever waits for chunks that a running helper has claimed, and takes the unclaimed ones itself -- so a
+            // launch that is not fully resident (workgroups that start late, or never) cannot stall anybody.
+            const int quit = until_all_done && AT_LOAD(sh.queue) >= sh.n_units && AT_LOAD(sh.active) <= 0;
             for (int base = 0; !quit && owner < 0 && base < sh.n_blocks; base += 64) {
                 const int b = base + B.lane;
                 unsigned long long w = b < sh.n_blocks ? AT_LOAD(&sh.jobs[b].word) : 0ull;
@@ -416,6 +418,7 @@ __global__ __launch_bounds__(FIT_THREADS) void gm_cv_kernel(CvParams P)
         __syncthreads();
         const int q = s_unit;
         if (q >= P.n_units) break;                 // every wave of every workgroup reaches this
+        if (threadIdx.x == 0 && P.active) AT_ADD(P.active, 1);      // this workgroup owns a fit (see fs_help_loop)
         const int unit = P.order[q];
         const int cell = unit / P.n_folds, f = unit % P.n_folds;
         const FoldDev F = P.folds[f];
@@ -442,6 +445,7 @@ __global__ __launch_bounds__(FIT_THREADS) void gm_cv_kernel(CvParams P)
             P.fold_err[unit] = (S.status & ST_ABORT) ? __builtin_nan("") : sse;   // an aborted fit has no score
             P.status[unit] = S.status;
             if (P.counters) store_counters(P.counters + (size_t)unit * PAREBEN_NCOUNTERS, s_cnt);
+            if (P.active) AT_ADD(P.active, -1);
         }
     }
     fs_help_loop(B, sh, P.K, true);
@@ -907,7 +911,7 @@ extern "C" int pareben_ctx_run(pareben_ctx *c, int n_cells, const double *alpha,
     if (!binom && share_mode != 0) {
         CK(dmalloc(&d_jobs, (size_t)blocks)); CK(dmalloc(&d_active, (size_t)4));
         CK(hipMemsetAsync(d_jobs, 0, sizeof(FsJob) * (size_t)blocks, c->stream));
-        act_host[0] = blocks;
+        act_host[0] = 0;                                        // workgroups that currently own a fit
         CK(hipMemcpyAsync(d_active, act_host, sizeof act_host, hipMemcpyHostToDevice, c->stream));
     }
     CK(hipMemsetAsync(d_err, 0xFF, sizeof(double) * n_units, c->stream));       // NaN-poison

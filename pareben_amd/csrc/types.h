@@ -79,7 +79,7 @@ struct FsJob {
 enum { JOB_FULLSTAT = 0, JOB_SQ = 1 };
 struct FsShare {           // null jobs = sharing off
     FsJob *jobs;           // one per workgroup of the launch
-    int *active;           // workgroups that still own a fit or may pull one from the queue
+    int *active;           // workgroups that currently own a fit
     const int *queue;      // work-queue head (>= n_units: drained)
     int n_units, n_blocks, self;
     char *ws;              // workspace base / stride of the launch: a helper carves the owner's slot
