@@ -880,6 +880,161 @@ DEVNI void gm_add(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScal
     S.M = M + 1;
 }
 
+#ifndef PAREBEN_HOST_EMUL
+// S_in / Q_in update of one feature by one add (gm_sq_apply mode 1), with the products spelled out so
+// that the K-space sweep and the M-space tracking below round identically.
+DEV void gm_add_apply(double &sin, double &qin, double beta, double rowval, double a, double sii, double mui)
+{
+    const double mc = beta * rowval - beta * a;
+    sin = sin - mc * mc * sii;
+    qin = qin - mui * mc;
+}
+
+// The K-space half of a run of T consecutive adds: ONE sweep over the Gram rows of the (final) active
+// set instead of T.  For add t (active-set size M0 + t when it is applied, vector vb[t]) feature i needs
+// a_t[i] = sum_{j < M0+t} G[row_j][i] vb[t][j]; the vectors are staged zero-padded in LDS, so every thread
+// loads each row element once and feeds TT accumulators; the new features' own rows (the rows M0 .. M0+T-1
+// of the sweep) are picked up on the way.  Then the T updates are applied in order.  TT = T rounded up.
+template <int TT>
+DEV void gm_sq_batch(const Blk &B, const FoldDev &F, const GmWork &W, int K, int M0, int T, double beta)
+{
+    typedef double d2 __attribute__((ext_vector_type(2), aligned(8)));
+    typedef const d2 __attribute__((address_space(1))) *gptr_cd2;
+    const gptr_cc G = (gptr_cc)as_global(uni_ptr(F.G));
+    const int tid = B.tid, nthr = uni(B.nthr);
+    const int Mt = M0 + T;                                      // rows of the sweep
+    const int ldv = W.cap + 2;
+    const lptr_d lvb = as_lds(B.pool);                          // [TT][Mt] zero-padded vectors
+    const lptr_d lsc = as_lds(B.pool + TT * Mt);                // sii[TT], mui[TT]
+    const lptr_i lused = as_lds((int *)(B.pool + TT * Mt + 2 * TT));
+    blk_sync(B);
+    for (int e = tid; e < TT * Mt; e += nthr) {
+        const int t = e / Mt, j = e - t * Mt;
+        lvb[e] = (t < T && j < M0 + t) ? W.vb[(size_t)t * ldv + j] : 0.0;
+    }
+    for (int t = tid; t < TT; t += nthr) { lsc[t] = t < T ? W.bsc[t] : 0.0; lsc[TT + t] = t < T ? W.bsc[ADD_TB + t] : 0.0; }
+    for (int j = tid; j < Mt; j += nthr) lused[j] = W.rowid[j];
+    blk_sync(B);
+    K = uni(K);
+    const int Kp = K & ~1;
+    for (int ib = 0; ib < Kp; ib += 2 * nthr) {
+        const int i = ib + 2 * tid;
+        const unsigned off = (unsigned)((i < Kp ? i : Kp - 2) * 8);
+        d2 acc[TT], rowv[TT];
+#pragma unroll
+        for (int t = 0; t < TT; t++) { acc[t] = d2{0, 0}; rowv[t] = d2{0, 0}; }
+        int j = 0;
+        for (; j + 1 < M0; j += 2) {                            // rows of the old active set, two per trip
+            const d2 g0 = *(gptr_cd2)(G + (size_t)uni(lused[j]) * (size_t)K * 8 + off);
+            const d2 g1 = *(gptr_cd2)(G + (size_t)uni(lused[j + 1]) * (size_t)K * 8 + off);
+#pragma unroll
+            for (int t = 0; t < TT; t++) { acc[t] += g0 * lvb[t * Mt + j]; acc[t] += g1 * lvb[t * Mt + j + 1]; }
+        }
+        if (j < M0) {
+            const d2 g0 = *(gptr_cd2)(G + (size_t)uni(lused[j]) * (size_t)K * 8 + off);
+#pragma unroll
+            for (int t = 0; t < TT; t++) acc[t] += g0 * lvb[t * Mt + j];
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < TT; s2++) {                       // the new features' own rows: row M0+s2 feeds the adds after s2
+            if (s2 < T) {
+                const d2 g = *(gptr_cd2)(G + (size_t)uni(lused[M0 + s2]) * (size_t)K * 8 + off);
+                rowv[s2] = g;
+#pragma unroll
+                for (int t = s2 + 1; t < TT; t++) acc[t] += g * lvb[t * Mt + M0 + s2];
+            }
+        }
+        if (i < Kp) {
+            double s0 = W.Sin[i], q0 = W.Qin[i], s1 = W.Sin[i + 1], q1 = W.Qin[i + 1];
+#pragma unroll
+            for (int t = 0; t < TT; t++) {
+                if (t < T) {
+                    gm_add_apply(s0, q0, beta, rowv[t][0], acc[t][0], lsc[t], lsc[TT + t]);
+                    gm_add_apply(s1, q1, beta, rowv[t][1], acc[t][1], lsc[t], lsc[TT + t]);
+                }
+            }
+            W.Sin[i] = s0; W.Qin[i] = q0; W.Sin[i + 1] = s1; W.Qin[i + 1] = q1;
+        }
+    }
+    if ((K & 1) && tid == 0) {                                  // the odd last feature
+        const int i = K - 1;
+        double s0 = W.Sin[i], q0 = W.Qin[i];
+        for (int t = 0; t < T; t++) {
+            double a = 0;
+            for (int j = 0; j < M0 + t; j++) a += *(gptr_cd)(G + ((size_t)lused[j] * (size_t)K + i) * 8) * lvb[t * Mt + j];
+            gm_add_apply(s0, q0, beta, *(gptr_cd)(G + ((size_t)lused[M0 + t] * (size_t)K + i) * 8), a, lsc[t], lsc[TT + t]);
+        }
+        W.Sin[i] = s0; W.Qin[i] = q0;
+    }
+    blk_sync(B);
+}
+
+// A run of T (2 .. ADD_TB) consecutive ADD actions of one block update = gm_add applied T times
+// (MainEff.c:1585-1723 + :613-627), restructured: the M-space part of every add (Sigma border, mu) runs in
+// sequence as before, but the K-space part -- each add's sweep over all Gram rows, which is what an action
+// costs -- is deferred and done for the whole run in ONE sweep (gm_sq_batch).  The only K-space values the
+// M-space part needs in between are S_in / Q_in of the run's own features (sii, mui of the later adds):
+// those T values are tracked on the side with the same arithmetic (one lane per feature, rows in order).
+// W.rowid[M0 .. M0+T) must already hold the Gram row ids of the run's features.
+DEVNI void gm_add_batch(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScalars &S, const int *nus, int T)
+{
+    const int M0 = S.M, ld = W.ld, ldv = W.cap + 2;
+    const double beta = S.beta;
+    double *sii_v = W.bsc, *mui_v = W.bsc + ADD_TB, *sin_v = W.bsc + 2 * ADD_TB, *qin_v = W.bsc + 3 * ADD_TB;
+    blk_sync(B);
+    if (B.tid < T) { sin_v[B.tid] = W.Sin[nus[B.tid]]; qin_v[B.tid] = W.Qin[nus[B.tid]]; }
+    blk_sync(B);
+    for (int t = 0; t < T; t++) {
+        const int M = M0 + t, nu = nus[t], rid = W.rowid[M];
+        const double newA = W.aroot[nu];
+        const double *row = F.G + (size_t)rid * K;
+        double *v2 = W.vb + (size_t)t * ldv;
+        PAR(l, M) W.v1[l] = beta * row[W.used[l]];
+        blk_sync(B);
+        PAR(i, M) {
+            double a = 0;
+            for (int j = 0; j < M; j++) a += W.Sig[(size_t)i * ld + j] * W.v1[j];
+            v2[i] = a;
+        }
+        const double sii = 1.0 / (newA + sin_v[t]);
+        const double mui = sii * qin_v[t];
+        blk_sync(B);
+        PAR(i, M) W.mu[i] += -mui * v2[i];
+        for (int j = B.wave; j < M; j += B.nwave) {
+            const double f = sii * v2[j];
+            for (int i = B.lane; i < M; i += BLK_LANES) W.Sig[(size_t)j * ld + i] += f * v2[i];
+        }
+        PAR(i, M) {
+            const double si = -sii * v2[i];
+            W.Sig[(size_t)M * ld + i] = si;
+            W.Sig[(size_t)i * ld + M] = si;
+        }
+        if (B.tid == 0) {
+            W.Sig[(size_t)M * ld + M] = sii;
+            W.A[M] = newA;
+            W.mu[M] = mui;
+            W.used[M] = nu;
+            W.upos[nu] = M;
+            sii_v[t] = sii; mui_v[t] = mui;
+        }
+        // S_in / Q_in of the run's later features after this add: lane 0 of wave (u - t - 1) mod nwave
+        for (int u = t + 1 + B.wave; u < T; u += B.nwave) {
+            if (B.lane == 0) {
+                const int fu = nus[u];
+                double a = 0;
+                for (int j = 0; j < M; j++) a += F.G[(size_t)W.rowid[j] * K + fu] * v2[j];
+                gm_add_apply(sin_v[u], qin_v[u], beta, row[fu], a, sii, mui);
+            }
+        }
+        blk_sync(B);
+    }
+    if (T <= 4) gm_sq_batch<4>(B, F, W, K, M0, T, beta);
+    else if (T <= 8) gm_sq_batch<8>(B, F, W, K, M0, T, beta);
+    else gm_sq_batch<ADD_TB>(B, F, W, K, M0, T, beta);
+    S.M = M0 + T;
+}
+#endif
+
 // delete slot jj, MainEff.c:1725-1822 + :640-651.  `nu` is the feature the action named; it
 // differs from used[jj] only on the reference's stale-slot path.
 DEVNI void gm_delete(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScalars &S, int jj, int nu)
@@ -1191,6 +1346,38 @@ DEV int gm_inner(const Blk &B, const FoldDev &F, const GmWork &W, int K, double 
             for (int u = 0; u < n_todo; u++) {
                 nu = W.todo[u];
                 sel = W.act[nu];
+#ifndef PAREBEN_HOST_EMUL
+                if (sel == ACT_ADD) {                             // a run of consecutive adds: one Gram-row sweep for all
+                    int T = 1;
+                    while (u + T < n_todo && T < ADD_TB && W.act[W.todo[u + T]] == ACT_ADD) T++;
+                    if (S.M + T > W.cap) T = W.cap - S.M;       // the add that overflows is left to the single path below
+                    for (;;) {                                    // LDS of the sweep: TT zero-padded vectors of M0 + T
+                        const int TT = T <= 4 ? 4 : (T <= 8 ? 8 : ADD_TB), Mt = S.M + T;
+                        if (T < 2 || TT * Mt + 2 * TT + (Mt + 1) / 2 + 8 <= B.pool_n) break;
+                        T = T > 8 ? 8 : (T > 4 ? 4 : 1);
+                    }
+                    if (T >= 2) {
+                        bool ok = true;
+                        for (int t = 0; t < T && ok; t++) {
+                            const int rid = gm_row(B, F, W, K, W.todo[u + t]);
+                            if (rid < 0) ok = false;
+                            else if (B.tid == 0) W.rowid[S.M + t] = rid;
+                        }
+                        if (!ok) { S.status |= ST_OVERFLOW | ST_ABORT; return 1; }
+                        CNT(c.n_add += T; c.sum_m_action += (int64_t)T * S.M + (int64_t)T * (T - 1) / 2);
+                        gm_add_batch(B, F, W, K, S, W.todo + u, T);
+                        u += T - 1;
+                        nu = W.todo[u];
+                        sel = ACT_ADD;
+                        blk_sync(B);
+                        gm_refresh_out(B, W, K);
+                        PAR(i, S.M) W.gam[i] = 1 - W.A[i] * W.Sig[(size_t)i * ld + i];
+                        blk_sync(B);
+                        CNT(if (S.M > c.m_max) c.m_max = S.M);
+                        continue;
+                    }
+                }
+#endif
                 const double newA = W.aroot[nu];
                 if (sel == ACT_REEST || sel == ACT_DEL) {
                     const int l = W.upos[nu];

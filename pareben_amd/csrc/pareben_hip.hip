@@ -204,7 +204,7 @@ static WsLayout ws_layout(int K, int cap)
     size_t o = 0;
     L.offK = o;   o += align_up((size_t)K * (7 * sizeof(double) + 2 * sizeof(int) + 1), 256);
     L.offSig = o; o += align_up((size_t)2 * L.ld * L.ld * sizeof(double), 256);
-    L.offM = o;   o += align_up((size_t)(cap + 2) * (7 * sizeof(double) + 3 * sizeof(int)), 256);
+    L.offM = o;   o += align_up((size_t)(cap + 2) * ((7 + ADD_TB) * sizeof(double) + 3 * sizeof(int)) + 4 * ADD_TB * sizeof(double), 256);
     L.bytes = align_up(o, 4096);
     return L;
 }
@@ -225,6 +225,7 @@ __device__ inline GmWork ws_carve(char *base, int K, int cap, size_t offK, size_
     const int c1 = cap + 1;
     W.A = d; d += c1; W.mu = d; d += c1; W.gam = d; d += c1;
     W.v1 = d; d += c1; W.v2 = d; d += c1; W.v3 = d; d += c1; W.v4 = d; d += c1;
+    W.vb = d; d += (size_t)ADD_TB * (cap + 2); W.bsc = d; d += 4 * ADD_TB;
     W.used = (int *)d;
     W.rowid = W.used + c1;
     W.pfree = W.rowid + c1;

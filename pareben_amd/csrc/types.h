@@ -50,6 +50,8 @@ enum {
     ST_ABORT = 8          // fit stopped early (a state the reference leaves undefined)
 };
 
+#define ADD_TB 16         // consecutive ADD actions of one block update applied with ONE sweep of the Gram rows
+
 // Per-workgroup scratch in HBM (one slot per resident workgroup).
 struct GmWork {
     double *Sin, *Qin, *Sout, *Qout, *dml, *aroot, *bt;   // K each
@@ -57,6 +59,7 @@ struct GmWork {
     signed char *act;                                      // K
     double *Sig, *H;                                       // cap x cap, column-major, ld = cap
     double *A, *mu, *gam, *v1, *v2, *v3, *v4;              // cap+1 each
+    double *vb, *bsc;                                      // batched adds: ADD_TB vectors of cap+2, 4*ADD_TB scalars
     int *used;                                             // cap+1  feature of each active slot
     int *rowid;                                            // cap+1  Gram row id of each active slot
     int *pfree;                                            // lazy mode: [0] = n free, [1..] free private row ids
