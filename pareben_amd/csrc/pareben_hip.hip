@@ -931,8 +931,8 @@ extern "C" int pareben_ctx_run(pareben_ctx *c, int n_cells, const double *alpha,
     P.priv_rows = c->priv_rows; P.priv_base0 = nF * c->pool_rows;
     P.jobs = d_jobs; P.active = d_active;
     // with only a handful of fits per workgroup the longest fits decide the step time: share from the start
-    // (measured on config-2 shares: 1250 fits 2.59 -> 2.49 s; with 2500 or more fits it costs more than it gains)
-    P.early = (d_jobs && (share_mode == 2 || (share_mode < 0 && n_units < 6 * blocks))) ? 1 : 0;
+    // (measured on config-2 shares with 256 workgroups: 1250 fits 2.51 -> 2.27 s, 2500 fits 3.82 -> 3.55 s, 5000 fits 6.15 -> 6.37 s)
+    P.early = (d_jobs && (share_mode == 2 || (share_mode < 0 && n_units <= 10 * blocks))) ? 1 : 0;
     if (binom) {
         BmCvParams Q;
         Q.folds = c->d_folds; Q.alpha = d_alpha; Q.lambda = d_lambda; Q.order = d_order; Q.queue = d_queue;
