@@ -38,7 +38,7 @@ DEV int blk_scan_excl(const Blk &, int v, int *total) { *total = v; return 0; }
 struct Blk {
     int tid, nthr, lane, wave, nwave;
     double *red;     // LDS: >= 2*BLK_MAX_WAVES doubles
-    int *ired;       // LDS: >= 2*BLK_MAX_WAVES ints
+    int *ired;       // LDS: 4*BLK_MAX_WAVES ints (reductions use the first 2*BLK_MAX_WAVES)
     double *pool;    // LDS: pool_n doubles, owned by whichever phase is running
     int pool_n;
 };

@@ -881,6 +881,76 @@ DEVNI void gm_add(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScal
 }
 
 #ifndef PAREBEN_HOST_EMUL
+// Lazy Gram mode: rows of several features in ONE sweep of the fold's design (gm_row does one row per
+// sweep; a run of T adds needs T of them).  For every feature of `nus` that nobody has computed or is
+// computing, this workgroup claims the row (same protocol as gm_row), takes a pool slot, then sweeps the
+// design once with all claimed features' columns staged in LDS -- each design column is loaded once and
+// dotted with every staged column (same lane assignment and reduction as gm_row: identical values) --
+// and publishes the rows.  Anything it cannot claim (already there, in flight elsewhere, pool full) is
+// simply left to the gm_row calls that follow.
+#define ROWS_MAX 16
+DEVNI void gm_rows_prefetch(const Blk &B, const FoldDev &F, int K, const int *nus, int T)
+{
+    if (!F.lazy || T < 2) return;
+    const int N = F.N;
+    int cmax = B.pool_n / (N > 0 ? N : 1);                      // staged columns that fit in the LDS pool
+    if (cmax > ROWS_MAX) cmax = ROWS_MAX;
+    if (cmax < 2) return;
+    const lptr_i lfeat = as_lds(B.ired + 2 * BLK_MAX_WAVES), lslot = as_lds(B.ired + 2 * BLK_MAX_WAVES + ROWS_MAX);
+    blk_sync(B);
+    if (B.tid == 0) {
+        int c = 0;
+        for (int t = 0; t < T && c < cmax; t++) {
+            int *st = F.slot_of + nus[t];
+            int expect = -1;
+            if (ROW_LOAD(st) != -1 || !ROW_CAS(st, expect, -2)) continue;            // present or in flight: not ours
+            int my = -1;
+            if (ROW_LOAD(F.pool_next) < F.pool_rows) my = ROW_FETCH_ADD(F.pool_next, 1);
+            if (my < 0 || my >= F.pool_rows) { ROW_STORE(st, -1); break; }           // pool exhausted: leave it to gm_row
+            lfeat[c] = nus[t]; lslot[c] = my + F.pool_base; c++;
+        }
+        B.ired[0] = c;
+    }
+    blk_sync(B);
+    const int C = B.ired[0];
+    blk_sync(B);
+    if (C == 0) return;
+    for (int c = 0; c < C; c++) {
+        const double *xu = F.X + (size_t)lfeat[c] * N;
+        const double ru = F.rscale[lfeat[c]];
+        PAR(h, N) B.pool[c * N + h] = xu[h] * ru;
+    }
+    blk_sync(B);
+    double *Gw = const_cast<double *>(F.G);
+    for (int i = B.wave; i < K; i += B.nwave) {
+        const double *xi = F.X + (size_t)i * N;
+        double a[ROWS_MAX];
+#pragma unroll
+        for (int c = 0; c < ROWS_MAX; c++) a[c] = 0;
+        for (int h = B.lane; h < N; h += BLK_LANES) {
+            const double x = xi[h];
+#pragma unroll
+            for (int c = 0; c < ROWS_MAX; c++) if (c < C) a[c] += x * B.pool[c * N + h];
+        }
+        const double sc = F.scale[i];
+#pragma unroll
+        for (int c = 0; c < ROWS_MAX; c++) {
+            if (c < C) {
+                const double v = wave_sum(a[c]);
+                if (B.lane == 0) Gw[(size_t)lslot[c] * K + i] = v / sc;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains its stores
+    blk_sync(B);
+    if (B.tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int c = 0; c < C; c++) ROW_STORE(F.slot_of + lfeat[c], lslot[c]);
+    }
+    blk_sync(B);
+}
+
 // S_in / Q_in update of one feature by one add (gm_sq_apply mode 1), with the products spelled out so
 // that the K-space sweep and the M-space tracking below round identically.
 DEV void gm_add_apply(double &sin, double &qin, double beta, double rowval, double a, double sii, double mui)
@@ -1357,6 +1427,7 @@ DEV int gm_inner(const Blk &B, const FoldDev &F, const GmWork &W, int K, double 
                         T = T > 8 ? 8 : (T > 4 ? 4 : 1);
                     }
                     if (T >= 2) {
+                        gm_rows_prefetch(B, F, K, W.todo + u, T);   // lazy Gram mode: the run's missing rows in one design sweep
                         bool ok = true;
                         for (int t = 0; t < T && ok; t++) {
                             const int rid = gm_row(B, F, W, K, W.todo[u + t]);

@@ -301,7 +301,7 @@ struct CvParams {
 // LDS carve of one fit workgroup (dynamic shared memory): a phase-local pool (full-stat Gram
 // k-blocks and Sigma panels / inverse panels / action vectors) and the small reduction scratch.
 #define LDS_POOL_DOUBLES 16384
-#define LDS_FIT_BYTES ((LDS_POOL_DOUBLES + 2 * BLK_MAX_WAVES) * 8 + 2 * BLK_MAX_WAVES * 4)
+#define LDS_FIT_BYTES ((LDS_POOL_DOUBLES + 2 * BLK_MAX_WAVES) * 8 + 4 * BLK_MAX_WAVES * 4)
 extern __shared__ double lds_dyn[];
 
 __device__ inline Blk make_blk()
