@@ -309,3 +309,24 @@ def test_paper_epistasis_dataset_vs_oracle(oracle):
     Eo, _, rc = oracle.cv_grid(X, y, fid, 5, alpha[sel], lam[sel], epis=True, n_threads=8)
     assert rc == 0 and m[sel].max() >= 20
     assert _rel(E[sel], Eo).max() < 1e-6                       # active sets close to N = 160: ill-conditioned, observed <= 6e-8
+
+
+def test_config2_cells_vs_oracle_fixture():
+    """BASELINE config 2 at full size (synthetic n=1000, p=10000, nFolds=5): eight cells spread over the
+    grid against the oracle's committed table (tools/make_config2_golden.py: tens of CPU-minutes, so a
+    fixture): fold SSE <= 1e-8 relative and the same add / delete / re-estimate / full-stat counts."""
+    import os
+    from pareben_amd.synth import synthetic_gaussian as synth
+    path = os.path.join(os.path.dirname(__file__), "golden", "config2_cells.npz")
+    if not os.path.exists(path):
+        pytest.skip("fixture not generated")
+    g = np.load(path)
+    X, y, _, _ = synth(1000, 10000)
+    with pareben_amd.Context(X, y, g["fold_id"], 5) as ctx:
+        E, st, cnt = ctx.run(g["alpha"], g["lam"])
+    assert np.all(st & 8 == 0)
+    assert _rel(E, g["fold_err"]).max() < 1e-8
+    want = dict(zip([str(s) for s in g["counter_names"]], g["counters"]))
+    tot = cnt.sum(axis=(0, 1))
+    for j, n in enumerate(("n_outer", "n_inner", "n_add", "n_del", "n_reest", "n_fullstat")):
+        assert tot[j] == want[n], n
