@@ -88,7 +88,8 @@ int pareben_ctx_create(pareben_ctx **out, int device,
  * In the tail of a launch (work queue drained) workgroups without a fit take over feature tiles of the
  * full-stat passes and action mat-vecs of the fits still running; results are bit-identical either way.
  * PAREBEN_SHARE=0 (read by pareben_ctx_run) turns that off, 1 keeps it to the tail, 2 shares from the
- * start; unset = automatic (diagnostics / A-B timing).
+ * start; unset = automatic (diagnostics / A-B timing).  PAREBEN_HEAVY_M=<active-set size> (default 384) is
+ * the size from which a fit shares its phases whatever the state of the queue.
  */
 int pareben_ctx_run(pareben_ctx *ctx, int n_cells, const double *alpha, const double *lambda,
                     double *fold_err, int32_t *status, int64_t *counters);

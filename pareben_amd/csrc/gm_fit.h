@@ -403,7 +403,9 @@ DEV bool job_share(const Blk &B, GmScalars &S, int kind, int M, int n_tiles, dou
     const int chunk = job_chunk(kind);
     if (!(sh && sh->jobs) || n_tiles < 4 * chunk) return false;
     __syncthreads();
-    if (B.tid == 0) B.ired[0] = sh->early || AT_LOAD(sh->queue) >= sh->n_units;   // somebody may be free to help
+    // somebody may be free to help: always in the tail; from the start when the launch is small or the fit is a
+    // heavy one (large active set: the few fits that decide the step time once the work is spread over GPUs)
+    if (B.tid == 0) B.ired[0] = sh->early || M >= sh->heavy_m || AT_LOAD(sh->queue) >= sh->n_units;
     __syncthreads();
     const bool open = B.ired[0] != 0;
     __syncthreads();

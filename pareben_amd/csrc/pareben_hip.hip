@@ -295,6 +295,7 @@ struct CvParams {
     FsJob *jobs;                       // shared phases (gm_fit.h); null = off
     int *active;
     int early;                         // share from the start (few fits per workgroup)
+    int heavy_m;                       // active-set size from which a fit shares its phases from the start
     GmVariant v;
 };
 
@@ -411,9 +412,9 @@ __global__ __launch_bounds__(FIT_THREADS) void gm_cv_kernel(CvParams P)
     FsShare sh;
     sh.jobs = P.jobs; sh.active = P.active; sh.queue = P.queue; sh.n_units = P.n_units; sh.n_blocks = gridDim.x;
     sh.self = blockIdx.x; sh.ws = P.ws; sh.ws_stride = P.ws_stride; sh.offK = P.offK; sh.offSig = P.offSig; sh.offM = P.offM;
-    sh.folds = P.folds; sh.cap = P.cap; sh.early = P.early;
+    sh.folds = P.folds; sh.cap = P.cap; sh.early = P.early; sh.heavy_m = P.heavy_m;
     for (int n_done = 0;; n_done++) {
-        if (P.early && n_done > 0) fs_help_loop(B, sh, P.K, false);   // between fits: lend a hand to the long ones
+        if (n_done > 0) fs_help_loop(B, sh, P.K, false);            // between fits: lend a hand to the long ones
         __syncthreads();
         if (threadIdx.x == 0) s_unit = atomicAdd(P.queue, 1);
         __syncthreads();
@@ -933,6 +934,7 @@ extern "C" int pareben_ctx_run(pareben_ctx *c, int n_cells, const double *alpha,
     // with only a handful of fits per workgroup the longest fits decide the step time: share from the start
     // (measured on config-2 shares with 256 workgroups: 1250 fits 2.51 -> 2.27 s, 2500 fits 3.82 -> 3.55 s, 5000 fits 6.15 -> 6.37 s)
     P.early = (d_jobs && (share_mode == 2 || (share_mode < 0 && n_units <= 10 * blocks))) ? 1 : 0;
+    { const char *hm = getenv("PAREBEN_HEAVY_M"); P.heavy_m = share_mode == 1 ? (1 << 30) : (hm ? atoi(hm) : 384); }
     if (binom) {
         BmCvParams Q;
         Q.folds = c->d_folds; Q.alpha = d_alpha; Q.lambda = d_lambda; Q.order = d_order; Q.queue = d_queue;

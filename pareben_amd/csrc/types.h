@@ -90,4 +90,5 @@ struct FsShare {           // null jobs = sharing off
     const FoldDev *folds;
     int cap;
     int early;             // few fits per workgroup: phases are shared from the start, not only once the queue is drained
+    int heavy_m;           // fits whose active set reaches this size share their phases from then on
 };
