@@ -86,19 +86,62 @@ DEVNI void bm_weighted_rows(const Blk &B, const FoldDev &F, const BmWork &W, int
             W.BP[(size_t)i * ld + p] = a / F.scale[i];
         }
 #else
-    for (int i = B.wave; i < K; i += B.nwave) {
-        const double *x = F.X + (size_t)i * N;
-        for (int p = 0; p < M; p++) {
-            double a = 0;
-            if (p == 0) { for (int h = B.lane; h < N; h += 64) a += x[h] * W.w[h]; }
-            else {
-                const int u = W.used[p - 1];
-                const double *xu = F.X + (size_t)u * N;
-                const double r = F.rscale[u];
-                for (int h = B.lane; h < N; h += 64) a += (x[h] * W.w[h]) * (xu[h] * r);
+    // A small GEMM, X' (diag(w) Phi).  The weighted model columns Z_p = w .* Phi_p are staged in LDS (as many
+    // columns as fit, sample-contiguous), so the per-column work of a feature is "coalesced design column
+    // (L1-resident after the first column) x LDS column + one wave reduction", with no dependent
+    // used[] -> rscale[] -> column address chain per column.
+    int pcn = B.pool_n / N;
+    if (pcn > M) pcn = M;
+    if (pcn >= 1) {
+        double *Z = B.pool;                                    // [pcn][N]
+        for (int p0 = 0; p0 < M; p0 += pcn) {
+            const int pn = M - p0 < pcn ? M - p0 : pcn;
+            blk_sync(B);
+            for (int e = B.tid; e < N * pn; e += B.nthr) {
+                const int pc = e / N, h = e - pc * N, p = p0 + pc;
+                Z[e] = W.w[h] * BM_PHI(p, h);
             }
-            a = wave_sum(a);
-            if (B.lane == 0) W.BP[(size_t)i * ld + p] = a / F.scale[i];
+            blk_sync(B);
+            for (int i = B.wave; i < K; i += B.nwave) {
+                const double *x = F.X + (size_t)i * N;
+                const double rsc = 1.0 / F.scale[i];
+                if (N <= 8 * 64) {                             // the design column lives in registers for all pn columns
+                    double xr[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) xr[k] = (B.lane + 64 * k < N) ? x[B.lane + 64 * k] : 0.0;
+                    for (int pc = 0; pc < pn; pc++) {
+                        const double *z = Z + pc * N;
+                        double a = 0;
+#pragma unroll
+                        for (int k = 0; k < 8; k++) if (B.lane + 64 * k < N) a += xr[k] * z[B.lane + 64 * k];
+                        a = wave_sum(a);
+                        if (B.lane == 0) W.BP[(size_t)i * ld + p0 + pc] = a * rsc;
+                    }
+                } else {
+                    for (int pc = 0; pc < pn; pc++) {
+                        double a = 0;
+                        for (int h = B.lane; h < N; h += 64) a += x[h] * Z[pc * N + h];
+                        a = wave_sum(a);
+                        if (B.lane == 0) W.BP[(size_t)i * ld + p0 + pc] = a * rsc;
+                    }
+                }
+            }
+        }
+    } else {
+        for (int i = B.wave; i < K; i += B.nwave) {            // samples do not fit in LDS: columns from memory
+            const double *x = F.X + (size_t)i * N;
+            for (int p = 0; p < M; p++) {
+                double a = 0;
+                if (p == 0) { for (int h = B.lane; h < N; h += 64) a += x[h] * W.w[h]; }
+                else {
+                    const int u = W.used[p - 1];
+                    const double *xu = F.X + (size_t)u * N;
+                    const double r = F.rscale[u];
+                    for (int h = B.lane; h < N; h += 64) a += (x[h] * W.w[h]) * (xu[h] * r);
+                }
+                a = wave_sum(a);
+                if (B.lane == 0) W.BP[(size_t)i * ld + p] = a / F.scale[i];
+            }
         }
     }
 #endif
@@ -217,13 +260,19 @@ DEVNI int bm_postmode(const Blk &B, const FoldDev &F, const BmWork &W, GmScalars
 DEVNI int bm_fullstat(const Blk &B, const FoldDev &F, const BmWork &W, int K, GmScalars &S)
 {
     const int N = F.N, ld = W.ld;
-    if (bm_postmode(B, F, W, S)) return 1;
+    { PH_BEGIN(); const int bad = bm_postmode(B, F, W, S); PH_END(PH_INVERSE); if (bad) return 1; }
     const int M = S.M;
+    PH_BEGIN();
     bm_phi_mu(B, F, W, M, W.mu, W.pm);
     PAR(h, N) { const double y = 1 / (1 + exp(-W.pm[h])); W.e[h] = F.y[h] - y; }
     blk_sync(B);
     bm_weighted_rows(B, F, W, K, M);
+    PH_END(PH_FS_FEAT);
     // S_in = x_i' diag(w) x_i / |x_i|^2 - BP_i' Sigma BP_i ;  Q_in = x_i' e / |x_i|
+    long long ph_t1_ = 0;
+#if defined(PAREBEN_PHASE_TIMERS) && !defined(PAREBEN_HOST_EMUL)
+    if (B.tid == 0) ph_t1_ = (long long)wall_clock64();
+#endif
 #ifdef PAREBEN_HOST_EMUL
     for (int i = 0; i < K; i++) {
         double bbq = 0, ze = 0;
@@ -260,6 +309,10 @@ DEVNI int bm_fullstat(const Blk &B, const FoldDev &F, const BmWork &W, int K, Gm
         else { W.Sout[i] = s; W.Qout[i] = q; }
     }
     blk_sync(B);
+#if defined(PAREBEN_PHASE_TIMERS) && !defined(PAREBEN_HOST_EMUL)
+    if (B.tid == 0) S.ph[PH_FS_REST] += (long long)wall_clock64() - ph_t1_;
+#endif
+    (void)ph_t1_;
     CNT(c.n_fullstat++; c.sum_m_full += M; c.sum_m2_full += (int64_t)M * M);
     return 0;
 }
@@ -530,7 +583,8 @@ DEV int bm_inner(const Blk &B, const FoldDev &F, const BmWork &W, int K, double 
         CNT(c.n_inner++);
         ll0 = ll;
         double best; int any_del;
-        int nu = bm_delta_ml(B, W, K, N, S.M - 1, lambda, alpha, &any_del, &best);
+        int nu;
+        { PH_BEGIN(); nu = bm_delta_ml(B, W, K, N, S.M - 1, lambda, alpha, &any_del, &best); PH_END(PH_DML); }
         int worthwhile;
         if (sel == ACT_TERM && !ini_removed && S.M > 2) nu = -1;
         if (nu == -1 && ini_removed) { worthwhile = 0; sel = ACT_TERM; }
@@ -562,6 +616,7 @@ DEV int bm_inner(const Blk &B, const FoldDev &F, const BmWork &W, int K, double 
                 }
                 if (sel == ACT_REEST && fabs(log(newA) - log(W.A[jj])) <= 1e-3 && any_del == 0) sel = ACT_TERM;
                 blk_sync(B);
+                PH_BEGIN();
                 if (sel == ACT_REEST) {
                     CNT(c.n_reest++; c.sum_m_action += S.M);
                     bm_reestimate(B, F, W, K, S, jj, newA);
@@ -574,6 +629,7 @@ DEV int bm_inner(const Blk &B, const FoldDev &F, const BmWork &W, int K, double 
                     bm_delete(B, F, W, K, S, jj, nu);
                     if (nu == initial) ini_removed = 1;
                 }
+                PH_END(PH_ACTION);
                 CNT(if (S.M > c.m_max) c.m_max = S.M);
                 if (u == n_todo - 1) {                         // :749-762
                     if (bm_fullstat(B, F, W, K, S)) { S.status |= ST_CHOLESKY | ST_ABORT; return 1; }

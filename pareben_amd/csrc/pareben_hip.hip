@@ -464,6 +464,7 @@ struct BmCvParams {
     char *ws;
     BmLayout L;
     int K, n_folds, n_units;
+    long long *phase;      // [n_units x 8] diagnostic ticks, may be null
 };
 
 __global__ __launch_bounds__(FIT_THREADS) void bm_cv_kernel(BmCvParams P)
@@ -484,9 +485,20 @@ __global__ __launch_bounds__(FIT_THREADS) void bm_cv_kernel(BmCvParams P)
         const FoldDev F = P.folds[f];
         GmScalars S;
         S.c = &s_cnt; S.ph = s_ph;
+#ifdef PAREBEN_PHASE_TIMERS
+        if (threadIdx.x < 8) s_ph[threadIdx.x] = 0;
+        __syncthreads();
+        const long long t_fit0 = wall_clock64();
+#endif
         double ll;
         bm_fit(B, F, W, P.K, P.lambda[cell], P.alpha[cell], S, &ll);
         const double score = bm_fold_loglik(B, F, W, S);
+#ifdef PAREBEN_PHASE_TIMERS
+        if (threadIdx.x == 0 && P.phase) {
+            s_ph[PH_TOTAL] = wall_clock64() - t_fit0;
+            for (int k = 0; k < 8; k++) P.phase[(size_t)unit * 8 + k] = s_ph[k];
+        }
+#endif
         if (threadIdx.x == 0) {
             P.fold_err[unit] = (S.status & ST_ABORT) ? __builtin_nan("") : score;
             P.status[unit] = S.status;
@@ -939,7 +951,7 @@ extern "C" int pareben_ctx_run(pareben_ctx *c, int n_cells, const double *alpha,
         BmCvParams Q;
         Q.folds = c->d_folds; Q.alpha = d_alpha; Q.lambda = d_lambda; Q.order = d_order; Q.queue = d_queue;
         Q.fold_err = d_err; Q.status = d_status; Q.counters = d_cnt; Q.ws = c->d_ws; Q.L = c->BL;
-        Q.K = c->p; Q.n_folds = nF; Q.n_units = n_units;
+        Q.K = c->p; Q.n_folds = nF; Q.n_units = n_units; Q.phase = d_phase;
         hipLaunchKernelGGL(bm_cv_kernel, dim3(blocks), dim3(FIT_THREADS), LDS_FIT_BYTES, c->stream, Q);
     } else {
         hipLaunchKernelGGL(gm_cv_kernel, dim3(blocks), dim3(FIT_THREADS), LDS_FIT_BYTES, c->stream, P);
