@@ -50,6 +50,37 @@ DEV double wave_sum(double v)
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// Eight wave-wide sums for the price of ten shuffles instead of forty-eight: at the 32/16/8 strides the two
+// partner lanes split the columns between them (each keeps half and adds the partner's half), the last three
+// strides finish the single column a lane is left with.  On return lane l with (l & 7) == 0 holds in v[0] the
+// total of column l >> 3.  The tree is fixed, so results do not depend on timing.
+DEV void wave_sum8(double (&v)[8], int lane)
+{
+    {
+        const bool up = lane & 32;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const double send = up ? v[c] : v[c + 4], keep = up ? v[c + 4] : v[c];
+            v[c] = keep + __shfl_xor(send, 32, 64);
+        }
+    }
+    {
+        const bool up = lane & 16;
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const double send = up ? v[c] : v[c + 2], keep = up ? v[c + 2] : v[c];
+            v[c] = keep + __shfl_xor(send, 16, 64);
+        }
+    }
+    {
+        const bool up = lane & 8;
+        const double send = up ? v[0] : v[1], keep = up ? v[1] : v[0];
+        v[0] = keep + __shfl_xor(send, 8, 64);
+    }
+    v[0] += __shfl_xor(v[0], 4, 64);
+    v[0] += __shfl_xor(v[0], 2, 64);
+    v[0] += __shfl_xor(v[0], 1, 64);
+}
 // block-wide sum, identical in every thread.  xor-butterfly inside a wave (every lane ends with
 // the same bits), then the per-wave partials are added in wave order by every thread.
 DEV double blk_sum(const Blk &B, double v)

@@ -109,13 +109,19 @@ DEVNI void bm_weighted_rows(const Blk &B, const FoldDev &F, const BmWork &W, int
                     double xr[8];
 #pragma unroll
                     for (int k = 0; k < 8; k++) xr[k] = (B.lane + 64 * k < N) ? x[B.lane + 64 * k] : 0.0;
-                    for (int pc = 0; pc < pn; pc++) {
-                        const double *z = Z + pc * N;
-                        double a = 0;
+                    for (int pc = 0; pc < pn; pc += 8) {       // eight columns per reduction tree (blk.h: wave_sum8)
+                        double a[8];
 #pragma unroll
-                        for (int k = 0; k < 8; k++) if (B.lane + 64 * k < N) a += xr[k] * z[B.lane + 64 * k];
-                        a = wave_sum(a);
-                        if (B.lane == 0) W.BP[(size_t)i * ld + p0 + pc] = a * rsc;
+                        for (int c = 0; c < 8; c++) {
+                            const double *z = Z + (pc + c < pn ? pc + c : pn - 1) * N;
+                            double t = 0;
+#pragma unroll
+                            for (int k = 0; k < 8; k++) if (B.lane + 64 * k < N) t += xr[k] * z[B.lane + 64 * k];
+                            a[c] = t;
+                        }
+                        wave_sum8(a, B.lane);
+                        const int c = B.lane >> 3;
+                        if ((B.lane & 7) == 0 && pc + c < pn) W.BP[(size_t)i * ld + p0 + pc + c] = a[0] * rsc;
                     }
                 } else {
                     for (int pc = 0; pc < pn; pc++) {
@@ -260,6 +266,7 @@ DEVNI int bm_postmode(const Blk &B, const FoldDev &F, const BmWork &W, GmScalars
 DEVNI int bm_fullstat(const Blk &B, const FoldDev &F, const BmWork &W, int K, GmScalars &S)
 {
     const int N = F.N, ld = W.ld;
+    S.bp_ok = 0;                                               // the weights change: cached weighted rows are stale
     { PH_BEGIN(); const int bad = bm_postmode(B, F, W, S); PH_END(PH_INVERSE); if (bad) return 1; }
     const int M = S.M;
     PH_BEGIN();
@@ -267,6 +274,7 @@ DEVNI int bm_fullstat(const Blk &B, const FoldDev &F, const BmWork &W, int K, Gm
     PAR(h, N) { const double y = 1 / (1 + exp(-W.pm[h])); W.e[h] = F.y[h] - y; }
     blk_sync(B);
     bm_weighted_rows(B, F, W, K, M);
+    S.bp_ok = M;
     PH_END(PH_FS_FEAT);
     // S_in = x_i' diag(w) x_i / |x_i|^2 - BP_i' Sigma BP_i ;  Q_in = x_i' e / |x_i|
     long long ph_t1_ = 0;
@@ -434,7 +442,9 @@ DEVNI void bm_add(const Blk &B, const FoldDev &F, const BmWork &W, int K, GmScal
     const double sii = 1.0 / (newA + W.Sin[nu]);
     const double mui = sii * W.Qin[nu];
     blk_sync(B);
-    bm_weighted_rows(B, F, W, K, M);                           // rows against the OLD model columns
+    // rows against the OLD model columns: still current from the last full-stat pass / action unless the
+    // weights changed in between (they only change in the posterior-mode step)
+    if (S.bp_ok != M) bm_weighted_rows(B, F, W, K, M);
     PAR(i, K) {
         const double *bp = W.BP + (size_t)i * ld;
         double t = 0;
@@ -442,7 +452,9 @@ DEVNI void bm_add(const Blk &B, const FoldDev &F, const BmWork &W, int K, GmScal
         const double mc = W.bb[i] - t;
         W.Sin[i] = W.Sin[i] - mc * mc * sii;
         W.Qin[i] = W.Qin[i] - mui * mc;
+        W.BP[(size_t)i * ld + M] = W.bb[i];                    // the new model column's weighted row entry
     }
+    S.bp_ok = M + 1;
     PAR(i, M) W.mu[i] += -mui * W.tp[i];
     for (int j = B.wave; j < M; j += B.nwave) {
         const double f = sii * W.tp[j];
@@ -473,14 +485,16 @@ DEVNI void bm_delete(const Blk &B, const FoldDev &F, const BmWork &W, int K, GmS
     const double sjj = W.tp[j1];
     const double mujj = W.mu[j1];
     const int gone = W.used[jj];
-    bm_weighted_rows(B, F, W, K, M);
+    if (S.bp_ok != M) bm_weighted_rows(B, F, W, K, M);
     PAR(i, K) {
         const double *bp = W.BP + (size_t)i * ld;
         double t = 0;
         for (int j = 0; j < M; j++) t += bp[j] * W.tp[j];
         W.Sin[i] = W.Sin[i] + t * t / sjj;
         W.Qin[i] = W.Qin[i] + t * mujj / sjj;
+        W.BP[(size_t)i * ld + j1] = W.BP[(size_t)i * ld + last];   // the last model column moves into the freed slot
     }
+    S.bp_ok = last;
     PAR(i, M) W.mu[i] = W.mu[i] - mujj * W.tp[i] / sjj;
     for (int j = B.wave; j < M; j += B.nwave) {
         const double vj = W.tp[j];
@@ -526,7 +540,7 @@ DEVNI void bm_reestimate(const Blk &B, const FoldDev &F, const BmWork &W, int K,
     blk_sync(B);
     PAR(i, M) W.tmp[i] = W.Sig[(size_t)j1 * ld + i];           // the updated row
     blk_sync(B);
-    bm_weighted_rows(B, F, W, K, M);
+    if (S.bp_ok != M) bm_weighted_rows(B, F, W, K, M);
     PAR(i, K) {
         const double *bp = W.BP + (size_t)i * ld;
         double t = 0;

@@ -57,6 +57,7 @@ struct GmScalars {
     FitCounters *c;    // one copy per workgroup (LDS), updated by thread 0 only
     const FsShare *share = nullptr;   // shared full-stat passes (device only; null = off)
     int fold = 0;
+    int bp_ok = 0;     // binomial: model columns for which the weighted rows BP are current (0 = stale)
 };
 #define CNT(stmt) do { if (B.tid == 0) { FitCounters &c = *S.c; stmt; } } while (0)
 
