@@ -821,14 +821,30 @@ DEVNI int gm_row(const Blk &B, const FoldDev &F, const GmWork &W, int K, int u)
         PAR(h, N) B.pool[h] = xu[h] * ru;
         blk_sync(B);
     }
+#ifdef PAREBEN_HOST_EMUL
     for (int i = B.wave; i < K; i += B.nwave) {
         const double *xi = F.X + (size_t)i * N;
         double a = 0;
-        if (in_lds) for (int h = B.lane; h < N; h += BLK_LANES) a += xi[h] * B.pool[h];
-        else for (int h = B.lane; h < N; h += BLK_LANES) a += xi[h] * (xu[h] * ru);
-        a = wave_sum(a);
+        for (int h = B.lane; h < N; h += BLK_LANES) a += xi[h] * (xu[h] * ru);
         if (B.lane == 0) row[i] = a / F.scale[i];
     }
+#else
+    // eight features per wave and reduction tree (wave_sum8 pairs lanes exactly like wave_sum: same bits)
+    for (int i0 = B.wave * 8; i0 < K; i0 += B.nwave * 8) {
+        double a[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const double *xi = F.X + (size_t)(i0 + c < K ? i0 + c : K - 1) * N;
+            double t = 0;
+            if (in_lds) for (int h = B.lane; h < N; h += BLK_LANES) t += xi[h] * B.pool[h];
+            else for (int h = B.lane; h < N; h += BLK_LANES) t += xi[h] * (xu[h] * ru);
+            a[c] = t;
+        }
+        wave_sum8(a, B.lane);
+        const int i = i0 + (B.lane >> 3);
+        if ((B.lane & 7) == 0 && i < K) row[i] = a[0] / F.scale[i];
+    }
+#endif
 #ifndef PAREBEN_HOST_EMUL
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its stores
 #endif
@@ -937,10 +953,14 @@ DEVNI void gm_rows_prefetch(const Blk &B, const FoldDev &F, int K, const int *nu
         }
         const double sc = F.scale[i];
 #pragma unroll
-        for (int c = 0; c < ROWS_MAX; c++) {
-            if (c < C) {
-                const double v = wave_sum(a[c]);
-                if (B.lane == 0) Gw[(size_t)lslot[c] * K + i] = v / sc;
+        for (int c0 = 0; c0 < ROWS_MAX; c0 += 8) {              // eight staged columns per reduction tree
+            if (c0 < C) {
+                double v[8];
+#pragma unroll
+                for (int c = 0; c < 8; c++) v[c] = a[c0 + c];
+                wave_sum8(v, B.lane);
+                const int c = c0 + (B.lane >> 3);
+                if ((B.lane & 7) == 0 && c < C) Gw[(size_t)lslot[c] * K + i] = v[0] / sc;
             }
         }
     }
