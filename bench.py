@@ -170,8 +170,10 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "synthetic gaussian n=%d p=%d nFolds=%d grid=%dalpha x %dlambda Epis=no (BASELINE configs[1])"
-                                   % (args.n, args.p, nF, args.nalpha, args.nlambda),
+            "config": {"workload": "synthetic gaussian n=%d p=%d nFolds=%d grid=%dalpha x %dlambda Epis=no%s"
+                                   % (args.n, args.p, nF, args.nalpha, args.nlambda,
+                                      " (BASELINE configs[1])" if (args.n, args.p, nF, args.nalpha, args.nlambda) == (1000, 10000, 5, 20, 100)
+                                      else " (reduced rehearsal size, not the BASELINE workload)"),
                        "fits_per_step": total_fits, "parallelism": "cells sharded over %d GPU(s)" % world,
                        "wall_to_optimum_s": elapsed / args.steps,
                        "alpha_opt": state["best"][0], "lambda_opt": state["best"][1], "cv_error": state["best"][2],
