@@ -1266,32 +1266,54 @@ DEVNI int gm_spd_inverse_blocked(const Blk &B, const GmWork &W, int M)
         __syncthreads();
         // A22 += Tn * A21'  on the lower-triangle tiles that do not touch the pivot block.
         // MFMA rows <-> j (column of A), MFMA columns <-> i (row of A): stores are contiguous in i.
-        int q = 0;
-        for (int ti = 0; ti < nT; ti++) {
-            if (ti == tk) continue;
-            for (int tj = 0; tj <= ti; tj++) {
-                if (tj == tk) continue;
-                if ((q++ % B.nwave) != B.wave) continue;
-                const int jrow = tj * 16 + l15;               // A-operand row  (column j of the matrix)
-                const int icol = ti * 16 + l15;               // B-operand / D column (row i of the matrix)
-                d4 acc;
+        // The tiles form a triangle over the nT - 1 non-pivot tile indices; tile number q = a (a + 1) / 2 + b
+        // (b <= a) goes to wave q mod nwave.  Each wave handles two of its tiles per trip so that the loads of
+        // both are in flight together (a tile on its own is one load -> matrix op -> store latency chain).
+        {
+            const int n1 = nT - 1, n_tiles = n1 * (n1 + 1) / 2;
+            for (int q0 = B.wave; q0 < n_tiles; q0 += 2 * B.nwave) {
+                d4 acc[2];
+                double av[2][4], bv[2][4];
+                int ti2[2], tj2[2];
+                bool on[2];
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int j = tj * 16 + l4 + 4 * r;
-                    acc[r] = (icol < M && j < M) ? Sig[(size_t)j * ld + icol] : 0.0;
+                for (int z = 0; z < 2; z++) {
+                    const int q = q0 + z * B.nwave;
+                    on[z] = q < n_tiles;
+                    const int qq = on[z] ? q : 0;
+                    int a = (int)((sqrt(8.0 * qq + 1.0) - 1.0) * 0.5);
+                    while ((a + 1) * (a + 2) / 2 <= qq) a++;
+                    while (a * (a + 1) / 2 > qq) a--;
+                    const int b = qq - a * (a + 1) / 2;
+                    ti2[z] = a < tk ? a : a + 1;                   // skip the pivot tile row / column
+                    tj2[z] = b < tk ? b : b + 1;
+                    const int jrow = tj2[z] * 16 + l15, icol = ti2[z] * 16 + l15;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int j = tj2[z] * 16 + l4 + 4 * r;
+                        acc[z][r] = (on[z] && icol < M && j < M) ? Sig[(size_t)j * ld + icol] : 0.0;
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < 4; kk++) {
+                        const int kc = k0 + kk * 4 + l4;
+                        double a_ = 0;
+                        if (on[z] && jrow < M && kc < M) a_ = (jrow > kc) ? Sig[(size_t)kc * ld + jrow] : Sig[(size_t)jrow * ld + kc];
+                        av[z][kk] = a_;
+                        bv[z][kk] = Tn[(size_t)icol * INV_TP + kk * 4 + l4];
+                    }
                 }
 #pragma unroll
-                for (int kk = 0; kk < 4; kk++) {
-                    const int kc = k0 + kk * 4 + l4;
-                    double av = 0;
-                    if (jrow < M && kc < M) av = (jrow > kc) ? Sig[(size_t)kc * ld + jrow] : Sig[(size_t)jrow * ld + kc];
-                    const double bv = Tn[(size_t)icol * INV_TP + kk * 4 + l4];
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-                }
+                for (int z = 0; z < 2; z++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int j = tj * 16 + l4 + 4 * r;
-                    if (icol < M && j < M) Sig[(size_t)j * ld + icol] = acc[r];
+                    for (int kk = 0; kk < 4; kk++) acc[z] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[z][kk], bv[z][kk], acc[z], 0, 0, 0);
+#pragma unroll
+                for (int z = 0; z < 2; z++) {
+                    const int icol = ti2[z] * 16 + l15;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int j = tj2[z] * 16 + l4 + 4 * r;
+                        if (on[z] && icol < M && j < M) Sig[(size_t)j * ld + icol] = acc[z][r];
+                    }
                 }
             }
         }
