@@ -1209,6 +1209,7 @@ DEVNI int gm_spd_inverse_scalar(const Blk &B, const GmWork &W, int M)
 // makes M/16 round trips through L2 instead of M.  LDS: Tn = -A21 A11^-1 (M x 16, pitch 18) and
 // the 16 x 16 pivot block.
 #define INV_TP 18
+#define INV_TT 2           // tiles of the trailing update each wave keeps in flight
 DEVNI int gm_spd_inverse_blocked(const Blk &B, const GmWork &W, int M)
 {
     const int ld = W.ld;
@@ -1267,17 +1268,17 @@ DEVNI int gm_spd_inverse_blocked(const Blk &B, const GmWork &W, int M)
         // A22 += Tn * A21'  on the lower-triangle tiles that do not touch the pivot block.
         // MFMA rows <-> j (column of A), MFMA columns <-> i (row of A): stores are contiguous in i.
         // The tiles form a triangle over the nT - 1 non-pivot tile indices; tile number q = a (a + 1) / 2 + b
-        // (b <= a) goes to wave q mod nwave.  Each wave handles two of its tiles per trip so that the loads of
-        // both are in flight together (a tile on its own is one load -> matrix op -> store latency chain).
+        // (b <= a) goes to wave q mod nwave.  Each wave handles INV_TT of its tiles per trip so that their loads
+        // are in flight together (a tile on its own is one load -> matrix op -> store latency chain).
         {
             const int n1 = nT - 1, n_tiles = n1 * (n1 + 1) / 2;
-            for (int q0 = B.wave; q0 < n_tiles; q0 += 2 * B.nwave) {
-                d4 acc[2];
-                double av[2][4], bv[2][4];
-                int ti2[2], tj2[2];
-                bool on[2];
+            for (int q0 = B.wave; q0 < n_tiles; q0 += INV_TT * B.nwave) {
+                d4 acc[INV_TT];
+                double av[INV_TT][4], bv[INV_TT][4];
+                int ti2[INV_TT], tj2[INV_TT];
+                bool on[INV_TT];
 #pragma unroll
-                for (int z = 0; z < 2; z++) {
+                for (int z = 0; z < INV_TT; z++) {
                     const int q = q0 + z * B.nwave;
                     on[z] = q < n_tiles;
                     const int qq = on[z] ? q : 0;
@@ -1303,11 +1304,11 @@ DEVNI int gm_spd_inverse_blocked(const Blk &B, const GmWork &W, int M)
                     }
                 }
 #pragma unroll
-                for (int z = 0; z < 2; z++)
+                for (int z = 0; z < INV_TT; z++)
 #pragma unroll
                     for (int kk = 0; kk < 4; kk++) acc[z] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[z][kk], bv[z][kk], acc[z], 0, 0, 0);
 #pragma unroll
-                for (int z = 0; z < 2; z++) {
+                for (int z = 0; z < INV_TT; z++) {
                     const int icol = ti2[z] * 16 + l15;
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
