@@ -1380,6 +1380,39 @@ DEVNI int gm_final_update(const Blk &B, const FoldDev &F, const GmWork &W, int K
     return 0;
 }
 
+// out_h = sum_j vec[j] * (X[used[j]][h] * rscale[used[j]])  for one sample h, the model columns in order.
+// On the device the (column id, coefficient, 1/|x|) triples are staged in LDS first (gm_stage_model), so
+// the only memory access per term is the coalesced design-column load and nothing sits behind a dependent
+// used[] -> rscale[] address chain; the arithmetic is the same expression in the same order either way.
+#ifdef PAREBEN_HOST_EMUL
+DEV void gm_stage_model(const Blk &, const FoldDev &, const GmWork &, int, const double *) {}
+DEV double gm_model_at(const Blk &, const FoldDev &F, const GmWork &W, int M, const double *vec, int N, int h)
+{
+    double v = 0;
+    for (int j = 0; j < M; j++) { const int uj = W.used[j]; v += vec[j] * (F.X[(size_t)uj * N + h] * F.rscale[uj]); }
+    return v;
+}
+#else
+DEV void gm_stage_model(const Blk &B, const FoldDev &F, const GmWork &W, int M, const double *vec)
+{
+    double *lc = B.pool, *lr = B.pool + M;
+    int *lu = (int *)(B.pool + 2 * M);
+    blk_sync(B);
+    PAR(j, M) { const int uj = W.used[j]; lu[j] = uj; lc[j] = vec[j]; lr[j] = F.rscale[uj]; }
+    blk_sync(B);
+}
+DEV double gm_model_at(const Blk &B, const FoldDev &F, const GmWork &, int M, const double *, int N, int h)
+{
+    const lptr_d lc = as_lds(B.pool), lr = as_lds(B.pool + M);
+    const lptr_i lu = as_lds((int *)(B.pool + 2 * M));
+    const gptr_cd X = as_global(F.X);
+    double v = 0;
+#pragma unroll 4
+    for (int j = 0; j < M; j++) v += lc[j] * (X[(size_t)lu[j] * N + h] * lr[j]);
+    return v;
+}
+#endif
+
 // One call of the inner routine (MainEff.c:248-809) for outer iteration `iter`.  On return
 // *cs = sum_i Csum_i and *csy = Csum.y with Csum the column sums of
 // C^-1 = beta I - beta^2 Phi Sigma Phi' (:741-781, :172-187), formed in O(N M + M^2).
@@ -1538,12 +1571,9 @@ DEV int gm_inner(const Blk &B, const FoldDev &F, const GmWork &W, int K, double 
             const int M = S.M;
             PH_BEGIN();
             double ee_part = 0;
+            gm_stage_model(B, F, W, M, W.mu);
             PAR(h, N) {
-                double pm = 0;
-                for (int j = 0; j < M; j++) {
-                    const int uj = W.used[j];
-                    pm += W.mu[j] * (F.X[(size_t)uj * N + h] * F.rscale[uj]);
-                }
+                const double pm = gm_model_at(B, F, W, M, W.mu, N, h);
                 const double e = (F.y[h] - S.b) - pm;
                 ee_part += e * e;
             }
@@ -1579,12 +1609,9 @@ DEV int gm_inner(const Blk &B, const FoldDev &F, const GmWork &W, int K, double 
         blk_sync(B);
         const double beta = S.beta, b2 = beta * beta;
         double a_part = 0, b_part = 0;
+        gm_stage_model(B, F, W, M, W.v2);
         PAR(h, N) {
-            double v = 0;
-            for (int j = 0; j < M; j++) {
-                const int uj = W.used[j];
-                v += W.v2[j] * (F.X[(size_t)uj * N + h] * F.rscale[uj]);
-            }
+            const double v = gm_model_at(B, F, W, M, W.v2, N, h);
             const double c = beta - b2 * v;
             a_part += c;
             b_part += c * F.y[h];
