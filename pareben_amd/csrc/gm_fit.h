@@ -1357,9 +1357,10 @@ DEVNI int gm_final_update(const Blk &B, const FoldDev &F, const GmWork &W, int K
 {
     const int M = S.M, ld = W.ld;
     const double beta = S.beta;
-    for (int j = B.wave; j < M; j += B.nwave) {
+#ifdef PAREBEN_HOST_EMUL
+    for (int j = 0; j < M; j++) {
         const int uj = W.used[j];
-        for (int i = B.lane; i < M; i += BLK_LANES) {
+        for (int i = 0; i < M; i++) {
             const int ui = W.used[i];
             // Phi_i.Phi_j from the Gram matrix; one triangle so that H is exactly symmetric
             double h = (i <= j ? F.G[(size_t)W.rowid[i] * K + uj] : F.G[(size_t)W.rowid[j] * K + ui]) * beta;
@@ -1368,6 +1369,28 @@ DEVNI int gm_final_update(const Blk &B, const FoldDev &F, const GmWork &W, int K
             W.Sig[(size_t)j * ld + i] = h;
         }
     }
+#else
+    {   // feature ids, Gram row ids and A staged in LDS: the M^2 gathers then depend on nothing but LDS
+        int *lu = (int *)B.pool, *lr = lu + M;
+        double *la = B.pool + M + 1;
+        blk_sync(B);
+        PAR(l, M) { lu[l] = W.used[l]; lr[l] = W.rowid[l]; la[l] = W.A[l]; }
+        blk_sync(B);
+        const gptr_cd G = as_global(F.G);
+        const gptr_d H = as_global_rw(W.H), Sg = as_global_rw(W.Sig);
+        for (int j = B.wave; j < M; j += B.nwave) {
+            const int uj = lu[j];
+            const size_t rj = (size_t)lr[j] * K;
+            for (int i = B.lane; i < M; i += BLK_LANES) {
+                // Phi_i.Phi_j from the Gram matrix; one triangle so that H is exactly symmetric
+                double h = (i <= j ? G[(size_t)lr[i] * K + uj] : G[rj + lu[i]]) * beta;
+                if (i == j) h += la[i];
+                H[(size_t)j * ld + i] = h;
+                Sg[(size_t)j * ld + i] = h;
+            }
+        }
+    }
+#endif
     PAR(l, M) W.v1[l] = W.bt[W.used[l]];
     blk_sync(B);
     { PH_BEGIN(); const int bad = gm_spd_inverse(B, W, M); PH_END(PH_INVERSE); if (bad) return 1; }
