@@ -45,7 +45,8 @@ enum { UP_FREE = -1, UP_LOST = -2 };
 #define PH_BEGIN() do {} while (0)
 #define PH_END(k) do {} while (0)
 #endif
-enum { PH_FS_FEAT = 0, PH_FS_REST = 1, PH_DML = 2, PH_ACTION = 3, PH_NOISE = 4, PH_INVERSE = 5, PH_FINAL_REST = 6, PH_TOTAL = 7 };
+enum { PH_FS_FEAT = 0, PH_FS_REST = 1, PH_DML = 2, PH_ACTION = 3, PH_NOISE = 4, PH_INVERSE = 5, PH_KSWEEP = 6, PH_TOTAL = 7,
+       PH_MATVEC = 8, PH_RANK1 = 9, PH_REFRESH = 10, PH_HBUILD = 11, PH_MU = 12, PH_TRACK = 13, PH_SSE = 14, PH_N = 16 };
 
 struct GmScalars {
     GmVariant v;       // main-effect / epistasis rule set
@@ -703,6 +704,7 @@ DEVNI void gm_sq_update(const Blk &B, const FoldDev &F, const GmWork &W, int K, 
         gm_sq_apply(W, mode, beta, c1, c2, newrow, i, a);
     }
 #else
+    PH_BEGIN();
     const gptr_cc G = (gptr_cc)as_global(uni_ptr(F.G));
     const lptr_d lvec = as_lds(B.pool);
     const lptr_i lused = as_lds((int *)(B.pool + ((M + 1) & ~1)));
@@ -722,8 +724,46 @@ DEVNI void gm_sq_update(const Blk &B, const FoldDev &F, const GmWork &W, int K, 
         for (int j = 0; j < M; j++) a += *(gptr_cd)(G + ((size_t)lused[j] * (size_t)K + (K - 1)) * 8) * lvec[j];
         gm_sq_apply(W, mode, beta, c1, c2, newrow, K - 1, a);
     }
+    PH_END(PH_KSWEEP);
 #endif
     blk_sync(B);
+}
+
+// Sigma[j][i] += a_j * b_i over the M x M block (the rank-1 update every action ends with), a_j = fa(j),
+// b_i = fb(i).  On the device both vectors are staged in LDS (at `scr`, 2 M doubles) and each wave keeps four
+// column chunks of b in registers while it walks its rows, so the only memory traffic is the coalesced
+// read-modify-write of Sigma with four loads in flight per wave; one fma per element either way.
+template <class FA, class FB>
+DEV void gm_rank1(const Blk &B, const GmWork &W, int M, double *scr, FA fa, FB fb)
+{
+    const int ld = W.ld;
+#ifdef PAREBEN_HOST_EMUL
+    (void)scr;
+    for (int j = 0; j < M; j++) {
+        const double f = fa(j);
+        for (int i = 0; i < M; i++) W.Sig[(size_t)j * ld + i] += f * fb(i);
+    }
+#else
+    const lptr_d la = as_lds(scr), lb = as_lds(scr + M);
+    blk_sync(B);
+    PAR(i, M) { la[i] = fa(i); lb[i] = fb(i); }
+    blk_sync(B);
+    const gptr_d Sg = as_global_rw(W.Sig);
+    const int lane = B.lane, wave = B.wave, nwave = B.nwave;
+    for (int i0 = 0; i0 < M; i0 += 4 * BLK_LANES) {
+        double br[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) { const int i = i0 + c * BLK_LANES + lane; br[c] = i < M ? lb[i] : 0.0; }
+        for (int j = wave; j < M; j += nwave) {
+            const double f = la[j];
+            double sv[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) { const int i = i0 + c * BLK_LANES + lane; sv[c] = i < M ? Sg[(size_t)j * ld + i] : 0.0; }
+#pragma unroll
+            for (int c = 0; c < 4; c++) { const int i = i0 + c * BLK_LANES + lane; if (i < M) Sg[(size_t)j * ld + i] = sv[c] + f * br[c]; }
+        }
+    }
+#endif
 }
 
 // re-estimate slot jj, MainEff.c:553-596
@@ -739,10 +779,9 @@ DEVNI void gm_reestimate(const Blk &B, const FoldDev &F, const GmWork &W, int K,
     blk_sync(B);
     if (B.tid == 0) W.A[jj] = newA;
     PAR(i, M) W.mu[i] += (-mujj * kappa) * W.v2[i];
-    for (int j = B.wave; j < M; j += B.nwave) {
-        const double f = kappa * W.v2[j];
-        for (int i = B.lane; i < M; i += BLK_LANES) W.Sig[(size_t)j * ld + i] -= f * W.v2[i];
-    }
+    { PH_BEGIN();
+    gm_rank1(B, W, M, B.pool, [&](int j) { return -(kappa * W.v2[j]); }, [&](int i) { return W.v2[i]; });
+    PH_END(PH_RANK1); }
     gm_sq_update(B, F, W, K, M, W.v2, 0, S.beta, kappa, mujj, -1, S);
 }
 
@@ -868,19 +907,20 @@ DEVNI void gm_add(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScal
     const double *row = F.G + (size_t)rid * K;                // x_i . phi_nu / scale_i (Gram row of nu)
     PAR(l, M) W.v1[l] = beta * row[W.used[l]];                // beta Phi' phi
     blk_sync(B);
+    { PH_BEGIN();
     PAR(i, M) {
         double a = 0;
         for (int j = 0; j < M; j++) a += W.Sig[(size_t)i * ld + j] * W.v1[j];
         W.v2[i] = a;                                          // Sigma * (beta Phi' phi)
     }
+    PH_END(PH_MATVEC); }
     const double sii = 1.0 / (newA + W.Sin[nu]);
     const double mui = sii * W.Qin[nu];
     blk_sync(B);
     PAR(i, M) W.mu[i] += -mui * W.v2[i];
-    for (int j = B.wave; j < M; j += B.nwave) {
-        const double f = sii * W.v2[j];
-        for (int i = B.lane; i < M; i += BLK_LANES) W.Sig[(size_t)j * ld + i] += f * W.v2[i];
-    }
+    { PH_BEGIN();
+    gm_rank1(B, W, M, B.pool, [&](int j) { return sii * W.v2[j]; }, [&](int i) { return W.v2[i]; });
+    PH_END(PH_RANK1); }
     PAR(i, M) {
         const double si = -sii * W.v2[i];
         W.Sig[(size_t)M * ld + i] = si;
@@ -1071,11 +1111,24 @@ DEV void gm_sq_batch(const Blk &B, const FoldDev &F, const GmWork &W, int K, int
 // W.rowid[M0 .. M0+T) must already hold the Gram row ids of the run's features.
 DEVNI void gm_add_batch(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScalars &S, const int *nus, int T)
 {
-    const int M0 = S.M, ld = W.ld, ldv = W.cap + 2;
+    const int M0 = S.M, ld = W.ld, ldv = W.cap + 2, Mt = M0 + T;
     const double beta = S.beta;
     double *sii_v = W.bsc, *mui_v = W.bsc + ADD_TB, *sin_v = W.bsc + 2 * ADD_TB, *qin_v = W.bsc + 3 * ADD_TB;
+    // LDS: gb[u][j] = G[row_j][nus[u]], the Gram values of the run's own features at every row of the final
+    // active set (gathered once, in parallel; the side tracking below then runs out of LDS), the current
+    // add's vector, and the scratch of the rank-1 update.
+    const lptr_d gb = as_lds(B.pool), lv2 = gb + (size_t)T * Mt;
+    double *scr = B.pool + (size_t)T * Mt + Mt;
+    const lptr_i lrow = as_lds((int *)scr);
+    const gptr_cd G = as_global(F.G);
     blk_sync(B);
     if (B.tid < T) { sin_v[B.tid] = W.Sin[nus[B.tid]]; qin_v[B.tid] = W.Qin[nus[B.tid]]; }
+    PAR(j, Mt) lrow[j] = W.rowid[j];
+    blk_sync(B);
+    for (int e = B.tid; e < T * Mt; e += B.nthr) {
+        const int u = e / Mt, j = e - u * Mt;
+        gb[e] = u >= 1 ? G[(size_t)lrow[j] * K + nus[u]] : 0.0;
+    }
     blk_sync(B);
     for (int t = 0; t < T; t++) {
         const int M = M0 + t, nu = nus[t], rid = W.rowid[M];
@@ -1084,19 +1137,34 @@ DEVNI void gm_add_batch(const Blk &B, const FoldDev &F, const GmWork &W, int K, 
         double *v2 = W.vb + (size_t)t * ldv;
         PAR(l, M) W.v1[l] = beta * row[W.used[l]];
         blk_sync(B);
+        { PH_BEGIN();
         PAR(i, M) {
             double a = 0;
             for (int j = 0; j < M; j++) a += W.Sig[(size_t)i * ld + j] * W.v1[j];
             v2[i] = a;
+            lv2[i] = a;
         }
+        PH_END(PH_MATVEC); }
         const double sii = 1.0 / (newA + sin_v[t]);
         const double mui = sii * qin_v[t];
         blk_sync(B);
         PAR(i, M) W.mu[i] += -mui * v2[i];
-        for (int j = B.wave; j < M; j += B.nwave) {
-            const double f = sii * v2[j];
-            for (int i = B.lane; i < M; i += BLK_LANES) W.Sig[(size_t)j * ld + i] += f * v2[i];
+        // S_in / Q_in of the run's later features after this add: lane 0 of wave (u - t - 1) mod nwave walks
+        // the rows in order (the same fma chain as the sweep in gm_sq_batch), operands from LDS
+        { PH_BEGIN();
+        for (int u = t + 1 + B.wave; u < T; u += B.nwave) {
+            if (B.lane == 0) {
+                const lptr_d gu = gb + (size_t)u * Mt;
+                double a = 0;
+#pragma unroll 8
+                for (int j = 0; j < M; j++) a += gu[j] * lv2[j];
+                gm_add_apply(sin_v[u], qin_v[u], beta, gu[M], a, sii, mui);
+            }
         }
+        PH_END(PH_TRACK); }
+        { PH_BEGIN();
+        gm_rank1(B, W, M, scr, [&](int j) { return sii * v2[j]; }, [&](int i) { return v2[i]; });
+        PH_END(PH_RANK1); }
         PAR(i, M) {
             const double si = -sii * v2[i];
             W.Sig[(size_t)M * ld + i] = si;
@@ -1110,20 +1178,13 @@ DEVNI void gm_add_batch(const Blk &B, const FoldDev &F, const GmWork &W, int K, 
             W.upos[nu] = M;
             sii_v[t] = sii; mui_v[t] = mui;
         }
-        // S_in / Q_in of the run's later features after this add: lane 0 of wave (u - t - 1) mod nwave
-        for (int u = t + 1 + B.wave; u < T; u += B.nwave) {
-            if (B.lane == 0) {
-                const int fu = nus[u];
-                double a = 0;
-                for (int j = 0; j < M; j++) a += F.G[(size_t)W.rowid[j] * K + fu] * v2[j];
-                gm_add_apply(sin_v[u], qin_v[u], beta, row[fu], a, sii, mui);
-            }
-        }
         blk_sync(B);
     }
+    PH_BEGIN();
     if (T <= 4) gm_sq_batch<4>(B, F, W, K, M0, T, beta);
     else if (T <= 8) gm_sq_batch<8>(B, F, W, K, M0, T, beta);
     else gm_sq_batch<ADD_TB>(B, F, W, K, M0, T, beta);
+    PH_END(PH_KSWEEP);
     S.M = M0 + T;
 }
 #endif
@@ -1141,10 +1202,7 @@ DEVNI void gm_delete(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmS
     const int gone_row = W.rowid[jj];
     gm_sq_update(B, F, W, K, M, W.v2, 2, S.beta, sjj, (double)mujj, -1, S);
     PAR(i, M) W.mu[i] = W.mu[i] - mujj * W.v2[i] / sjj;
-    for (int j = B.wave; j < M; j += B.nwave) {
-        const double vj = W.v2[j];
-        for (int i = B.lane; i < M; i += BLK_LANES) W.Sig[(size_t)j * ld + i] -= W.v2[i] / sjj * vj;
-    }
+    gm_rank1(B, W, M, B.pool, [&](int j) { return -W.v2[j]; }, [&](int i) { return W.v2[i] / sjj; });
     blk_sync(B);
     if (jj != last) {                                         // move the last slot into jj
         PAR(i, M) { W.v3[i] = W.Sig[(size_t)last * ld + i]; W.v4[i] = W.Sig[(size_t)i * ld + last]; }
@@ -1371,6 +1429,7 @@ DEVNI int gm_final_update(const Blk &B, const FoldDev &F, const GmWork &W, int K
     }
 #else
     {   // feature ids, Gram row ids and A staged in LDS: the M^2 gathers then depend on nothing but LDS
+        PH_BEGIN();
         int *lu = (int *)B.pool, *lr = lu + M;
         double *la = B.pool + M + 1;
         blk_sync(B);
@@ -1389,17 +1448,21 @@ DEVNI int gm_final_update(const Blk &B, const FoldDev &F, const GmWork &W, int K
                 Sg[(size_t)j * ld + i] = h;
             }
         }
+        blk_sync(B);
+        PH_END(PH_HBUILD);
     }
 #endif
     PAR(l, M) W.v1[l] = W.bt[W.used[l]];
     blk_sync(B);
     { PH_BEGIN(); const int bad = gm_spd_inverse(B, W, M); PH_END(PH_INVERSE); if (bad) return 1; }
+    PH_BEGIN();
     PAR(i, M) {
         double a = 0;
         for (int j = 0; j < M; j++) a += W.v1[j] * W.Sig[(size_t)j * ld + i];
         W.mu[i] = a * beta;
     }
     blk_sync(B);
+    PH_END(PH_MU);
     return 0;
 }
 
@@ -1525,7 +1588,7 @@ DEV int gm_inner(const Blk &B, const FoldDev &F, const GmWork &W, int K, double 
                     if (S.M + T > W.cap) T = W.cap - S.M;       // the add that overflows is left to the single path below
                     for (;;) {                                    // LDS of the sweep: TT zero-padded vectors of M0 + T
                         const int TT = T <= 4 ? 4 : (T <= 8 ? 8 : ADD_TB), Mt = S.M + T;
-                        if (T < 2 || TT * Mt + 2 * TT + (Mt + 1) / 2 + 8 <= B.pool_n) break;
+                        if (T < 2 || (TT * Mt + 2 * TT + (Mt + 1) / 2 + 8 <= B.pool_n && T * Mt + 3 * Mt <= B.pool_n)) break;
                         T = T > 8 ? 8 : (T > 4 ? 4 : 1);
                     }
                     if (T >= 2) {
@@ -1543,9 +1606,11 @@ DEV int gm_inner(const Blk &B, const FoldDev &F, const GmWork &W, int K, double 
                         nu = W.todo[u];
                         sel = ACT_ADD;
                         blk_sync(B);
+                        { PH_BEGIN();
                         gm_refresh_out(B, W, K);
                         PAR(i, S.M) W.gam[i] = 1 - W.A[i] * W.Sig[(size_t)i * ld + i];
                         blk_sync(B);
+                        PH_END(PH_REFRESH); }
                         CNT(if (S.M > c.m_max) c.m_max = S.M);
                         continue;
                     }
@@ -1582,9 +1647,11 @@ DEV int gm_inner(const Blk &B, const FoldDev &F, const GmWork &W, int K, double 
                 }
                 if (upd) {
                     blk_sync(B);
+                    { PH_BEGIN();
                     gm_refresh_out(B, W, K);
                     PAR(i, S.M) W.gam[i] = 1 - W.A[i] * W.Sig[(size_t)i * ld + i];
                     blk_sync(B);
+                    PH_END(PH_REFRESH); }
                     CNT(if (S.M > c.m_max) c.m_max = S.M);
                 }
             }

@@ -287,7 +287,7 @@ struct CvParams {
     double *fold_err;
     int *status;
     long long *counters;              // may be null
-    long long *phase;                 // [n_units x 8] diagnostic ticks, may be null
+    long long *phase;                 // [n_units x PH_N] diagnostic ticks, may be null
     char *ws;
     size_t ws_stride, offK, offSig, offM;
     int K, cap, n_folds, n_units;
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(FIT_THREADS) void gm_cv_kernel(CvParams P)
 {
     __shared__ int s_unit;
     __shared__ FitCounters s_cnt;
-    __shared__ long long s_ph[8];
+    __shared__ long long s_ph[PH_N];
     const Blk B = make_blk();
     GmWork W = ws_carve(P.ws + (size_t)blockIdx.x * P.ws_stride, P.K, P.cap, P.offK, P.offSig, P.offM);
     W.priv_rows = P.priv_rows;
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(FIT_THREADS) void gm_cv_kernel(CvParams P)
         S.share = &sh;
         S.fold = f;
 #ifdef PAREBEN_PHASE_TIMERS
-        if (threadIdx.x < 8) s_ph[threadIdx.x] = 0;
+        if (threadIdx.x < PH_N) s_ph[threadIdx.x] = 0;
         __syncthreads();
         const long long t_fit0 = wall_clock64();
 #endif
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(FIT_THREADS) void gm_cv_kernel(CvParams P)
 #ifdef PAREBEN_PHASE_TIMERS
         if (threadIdx.x == 0 && P.phase) {
             s_ph[PH_TOTAL] = wall_clock64() - t_fit0;
-            for (int k = 0; k < 8; k++) P.phase[(size_t)unit * 8 + k] = s_ph[k];
+            for (int k = 0; k < PH_N; k++) P.phase[(size_t)unit * PH_N + k] = s_ph[k];
         }
 #endif
         if (threadIdx.x == 0) {
@@ -464,14 +464,14 @@ struct BmCvParams {
     char *ws;
     BmLayout L;
     int K, n_folds, n_units;
-    long long *phase;      // [n_units x 8] diagnostic ticks, may be null
+    long long *phase;      // [n_units x PH_N] diagnostic ticks, may be null
 };
 
 __global__ __launch_bounds__(FIT_THREADS) void bm_cv_kernel(BmCvParams P)
 {
     __shared__ int s_unit;
     __shared__ FitCounters s_cnt;
-    __shared__ long long s_ph[8];
+    __shared__ long long s_ph[PH_N];
     const Blk B = make_blk();
     const BmWork W = bm_carve(P.ws + (size_t)blockIdx.x * P.L.bytes, P.K, P.L);
     for (;;) {
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(FIT_THREADS) void bm_cv_kernel(BmCvParams P)
         GmScalars S;
         S.c = &s_cnt; S.ph = s_ph;
 #ifdef PAREBEN_PHASE_TIMERS
-        if (threadIdx.x < 8) s_ph[threadIdx.x] = 0;
+        if (threadIdx.x < PH_N) s_ph[threadIdx.x] = 0;
         __syncthreads();
         const long long t_fit0 = wall_clock64();
 #endif
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(FIT_THREADS) void bm_cv_kernel(BmCvParams P)
 #ifdef PAREBEN_PHASE_TIMERS
         if (threadIdx.x == 0 && P.phase) {
             s_ph[PH_TOTAL] = wall_clock64() - t_fit0;
-            for (int k = 0; k < 8; k++) P.phase[(size_t)unit * 8 + k] = s_ph[k];
+            for (int k = 0; k < PH_N; k++) P.phase[(size_t)unit * PH_N + k] = s_ph[k];
         }
 #endif
         if (threadIdx.x == 0) {
@@ -527,7 +527,7 @@ struct FitParams {
 __global__ __launch_bounds__(FIT_THREADS) void gm_fit_kernel(FitParams P)
 {
     __shared__ FitCounters s_cnt;
-    __shared__ long long s_ph[8];
+    __shared__ long long s_ph[PH_N];
     const Blk B = make_blk();
     const GmWork W = ws_carve(P.ws, P.K, P.cap, P.offK, P.offSig, P.offM);
     const int K = P.K, p = P.p;
@@ -586,7 +586,7 @@ struct BmFitParams {
 __global__ __launch_bounds__(FIT_THREADS) void bm_fit_kernel(BmFitParams P)
 {
     __shared__ FitCounters s_cnt;
-    __shared__ long long s_ph[8];
+    __shared__ long long s_ph[PH_N];
     const Blk B = make_blk();
     const BmWork W = bm_carve(P.ws, P.K, P.L);
     const int K = P.K;
@@ -911,7 +911,7 @@ extern "C" int pareben_ctx_run(pareben_ctx *c, int n_cells, const double *alpha,
     CK(dmalloc(&d_queue, (size_t)1)); CK(dmalloc(&d_status, (size_t)n_units));
     if (counters) CK(dmalloc(&d_cnt, (size_t)n_units * PAREBEN_NCOUNTERS));
 #ifdef PAREBEN_PHASE_TIMERS
-    if (phase_path) { CK(dmalloc(&d_phase, (size_t)n_units * 8)); CK(hipMemsetAsync(d_phase, 0, sizeof(long long) * (size_t)n_units * 8, c->stream)); }
+    if (phase_path) { CK(dmalloc(&d_phase, (size_t)n_units * PH_N)); CK(hipMemsetAsync(d_phase, 0, sizeof(long long) * (size_t)n_units * PH_N, c->stream)); }
 #else
     (void)phase_path;
 #endif
@@ -967,7 +967,7 @@ extern "C" int pareben_ctx_run(pareben_ctx *c, int n_cells, const double *alpha,
     CK(hipStreamSynchronize(c->stream));
     if (status) for (int i = 0; i < n_units; i++) status[i] = st[i];
     if (d_phase) {
-        std::vector<long long> ph((size_t)n_units * 8);
+        std::vector<long long> ph((size_t)n_units * PH_N);
         CK(hipMemcpy(ph.data(), d_phase, sizeof(long long) * ph.size(), hipMemcpyDeviceToHost));
         if (FILE *fp = fopen(phase_path, "wb")) { fwrite(ph.data(), sizeof(long long), ph.size(), fp); fclose(fp); }
     }
