@@ -80,7 +80,9 @@ DEVNI void gm_refresh_out(const Blk &B, const GmWork &W, int K)
     blk_sync(B);
 }
 
-#ifndef PAREBEN_HOST_EMUL
+#ifdef PAREBEN_HOST_EMUL
+typedef double *lptr_d;
+#else
 // address-space-qualified views (global_load / ds_read instead of flat_load) for the hot loops
 typedef const double __attribute__((address_space(1))) *gptr_cd;
 typedef const char __attribute__((address_space(1))) *gptr_cc;
@@ -899,6 +901,87 @@ DEVNI int gm_row(const Blk &B, const FoldDev &F, const GmWork &W, int K, int u)
     return my;
 }
 
+// out[i] = sum_j Sigma[i][j] v[j], j ascending, one fma chain per row (the reference's loop order, so the
+// bits do not depend on how the work is laid out).  A thread per row reading its own row would touch 64
+// cache lines per wave-load; instead each wave takes 64 rows and moves them CW columns at a time through a
+// private LDS tile: coalesced 16-byte loads (CW/2 lanes per row), transposed by the tile (pitch CW+1,
+// conflict-free), then every lane walks its own row out of LDS.  The next chunk's loads are in flight while
+// the current one is summed.  scr: (M rounded up to 16) + nwave * 64 * (CW+1) doubles of LDS.
+#define MV_LDS(M, nwave, CW) ((((M) + 15) & ~15) + (nwave) * 64 * ((CW) + 1))
+template <int CW>
+DEV void gm_sigma_matvec(const Blk &B, const GmWork &W, int M, const double *v, double *out, double *scr, int scr_n, lptr_d out_lds)
+{
+    const int ld = W.ld;
+#ifdef PAREBEN_HOST_EMUL
+    (void)scr; (void)scr_n; (void)out_lds;
+    PAR(i, M) {
+        double a = 0;
+        for (int j = 0; j < M; j++) a += W.Sig[(size_t)i * ld + j] * v[j];
+        out[i] = a;
+    }
+#else
+    if (MV_LDS(M, B.nwave, CW) > scr_n) {                       // no room for the tiles: a thread per row
+        PAR(i, M) {
+            double a = 0;
+            for (int j = 0; j < M; j++) a += W.Sig[(size_t)i * ld + j] * v[j];
+            out[i] = a;
+            if (out_lds) out_lds[i] = a;
+        }
+        return;
+    }
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    typedef const d2 __attribute__((address_space(1))) *gptr_cd2;
+    constexpr int LPR = CW / 2, RPI = 64 / LPR, NI = 64 / RPI, TP = CW + 1;
+    const int lane = B.lane, wave = B.wave, nwave = B.nwave;
+    const lptr_d lv = as_lds(scr);
+    const lptr_d tile = lv + ((M + 15) & ~15) + wave * 64 * TP;
+    blk_sync(B);
+    PAR(j, M) lv[j] = v[j];
+    blk_sync(B);
+    const gptr_cd Sg = as_global(W.Sig);
+    const int lr = lane / LPR, lc = (lane % LPR) * 2;
+    for (int r0 = wave * 64; r0 < M; r0 += nwave * 64) {
+        size_t rowoff[NI];
+#pragma unroll
+        for (int q = 0; q < NI; q++) { int r = r0 + q * RPI + lr; if (r > M - 1) r = M - 1; rowoff[q] = (size_t)r * ld + lc; }
+        d2 nx[NI];
+#pragma unroll
+        for (int q = 0; q < NI; q++) nx[q] = *(gptr_cd2)(Sg + rowoff[q]);
+        double a = 0;
+        for (int j0 = 0; j0 < M; j0 += CW) {
+            d2 cur[NI];
+#pragma unroll
+            for (int q = 0; q < NI; q++) cur[q] = nx[q];
+            if (j0 + CW < M) {
+#pragma unroll
+                for (int q = 0; q < NI; q++) nx[q] = *(gptr_cd2)(Sg + rowoff[q] + j0 + CW);
+            }
+#pragma unroll
+            for (int q = 0; q < NI; q++) {
+                tile[(q * RPI + lr) * TP + lc] = cur[q][0];
+                tile[(q * RPI + lr) * TP + lc + 1] = cur[q][1];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0): the tile is written
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (j0 + CW <= M) {
+#pragma unroll
+                for (int c = 0; c < CW; c++) a += tile[lane * TP + c] * lv[j0 + c];
+            } else {
+#pragma unroll
+                for (int c = 0; c < CW; c++) if (j0 + c < M) a += tile[lane * TP + c] * lv[j0 + c];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_s_waitcnt(0xC07F);                 // the tile is consumed before it is overwritten
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        if (r0 + lane < M) { out[r0 + lane] = a; if (out_lds) out_lds[r0 + lane] = a; }
+    }
+#endif
+}
+
 // add feature nu, MainEff.c:1585-1723 + :613-627
 DEVNI void gm_add(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScalars &S, int nu, int rid, double newA)
 {
@@ -908,11 +991,7 @@ DEVNI void gm_add(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScal
     PAR(l, M) W.v1[l] = beta * row[W.used[l]];                // beta Phi' phi
     blk_sync(B);
     { PH_BEGIN();
-    PAR(i, M) {
-        double a = 0;
-        for (int j = 0; j < M; j++) a += W.Sig[(size_t)i * ld + j] * W.v1[j];
-        W.v2[i] = a;                                          // Sigma * (beta Phi' phi)
-    }
+    gm_sigma_matvec<16>(B, W, M, W.v1, W.v2, B.pool, B.pool_n, (lptr_d)0);    // Sigma * (beta Phi' phi)
     PH_END(PH_MATVEC); }
     const double sii = 1.0 / (newA + W.Sin[nu]);
     const double mui = sii * W.Qin[nu];
@@ -1138,12 +1217,7 @@ DEVNI void gm_add_batch(const Blk &B, const FoldDev &F, const GmWork &W, int K, 
         PAR(l, M) W.v1[l] = beta * row[W.used[l]];
         blk_sync(B);
         { PH_BEGIN();
-        PAR(i, M) {
-            double a = 0;
-            for (int j = 0; j < M; j++) a += W.Sig[(size_t)i * ld + j] * W.v1[j];
-            v2[i] = a;
-            lv2[i] = a;
-        }
+        gm_sigma_matvec<8>(B, W, M, W.v1, v2, scr, B.pool_n - T * Mt - Mt, lv2);
         PH_END(PH_MATVEC); }
         const double sii = 1.0 / (newA + sin_v[t]);
         const double mui = sii * qin_v[t];
@@ -1588,8 +1662,8 @@ DEV int gm_inner(const Blk &B, const FoldDev &F, const GmWork &W, int K, double 
                     if (S.M + T > W.cap) T = W.cap - S.M;       // the add that overflows is left to the single path below
                     for (;;) {                                    // LDS of the sweep: TT zero-padded vectors of M0 + T
                         const int TT = T <= 4 ? 4 : (T <= 8 ? 8 : ADD_TB), Mt = S.M + T;
-                        if (T < 2 || (TT * Mt + 2 * TT + (Mt + 1) / 2 + 8 <= B.pool_n && T * Mt + 3 * Mt <= B.pool_n)) break;
-                        T = T > 8 ? 8 : (T > 4 ? 4 : 1);
+                        if (T < 2 || (TT * Mt + 2 * TT + (Mt + 1) / 2 + 8 <= B.pool_n && T * Mt + Mt + MV_LDS(Mt, B.nwave, 8) <= B.pool_n)) break;
+                        T--;
                     }
                     if (T >= 2) {
                         gm_rows_prefetch(B, F, K, W.todo + u, T);   // lazy Gram mode: the run's missing rows in one design sweep
