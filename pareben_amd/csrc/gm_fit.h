@@ -41,12 +41,16 @@ enum { UP_FREE = -1, UP_LOST = -2 };
 #if defined(PAREBEN_PHASE_TIMERS) && !defined(PAREBEN_HOST_EMUL)
 #define PH_BEGIN() long long ph_t0_ = (B.tid == 0) ? (long long)wall_clock64() : 0
 #define PH_END(k) do { if (B.tid == 0) S.ph[k] += (long long)wall_clock64() - ph_t0_; } while (0)
+#define PHX_BEGIN(v) long long v = (B.tid == 0) ? (long long)wall_clock64() : 0
+#define PHX_END(v, k) do { if (B.tid == 0 && phx) phx[k] += (long long)wall_clock64() - v; } while (0)
 #else
 #define PH_BEGIN() do {} while (0)
 #define PH_END(k) do {} while (0)
+#define PHX_BEGIN(v) do {} while (0)
+#define PHX_END(v, k) do {} while (0)
 #endif
 enum { PH_FS_FEAT = 0, PH_FS_REST = 1, PH_DML = 2, PH_ACTION = 3, PH_NOISE = 4, PH_INVERSE = 5, PH_KSWEEP = 6, PH_TOTAL = 7,
-       PH_MATVEC = 8, PH_RANK1 = 9, PH_REFRESH = 10, PH_HBUILD = 11, PH_MU = 12, PH_TRACK = 13, PH_SSE = 14, PH_N = 16 };
+       PH_MATVEC = 8, PH_RANK1 = 9, PH_REFRESH = 10, PH_HBUILD = 11, PH_MU = 12, PH_TRACK = 13, PH_INV_PIVOT = 14, PH_INV_TN = 15, PH_N = 16 };
 
 struct GmScalars {
     GmVariant v;       // main-effect / epistasis rule set
@@ -1341,8 +1345,13 @@ DEVNI int gm_spd_inverse_scalar(const Blk &B, const GmWork &W, int M)
 // makes M/16 round trips through L2 instead of M.  LDS: Tn = -A21 A11^-1 (M x 16, pitch 18) and
 // the 16 x 16 pivot block.
 #define INV_TP 18
+#ifndef INV_TT
 #define INV_TT 2           // tiles of the trailing update each wave keeps in flight
-DEVNI int gm_spd_inverse_blocked(const Blk &B, const GmWork &W, int M)
+#endif
+#ifndef INV_RUN
+#define INV_RUN 4          // tiles per run (multiple of INV_TT)
+#endif
+DEVNI int gm_spd_inverse_blocked(const Blk &B, const GmWork &W, int M, long long *phx)
 {
     const int ld = W.ld;
     const gptr_d Sig = as_global_rw(W.Sig);
@@ -1353,6 +1362,7 @@ DEVNI int gm_spd_inverse_blocked(const Blk &B, const GmWork &W, int M)
     for (int tk = 0; tk < nT; tk++) {
         const int k0 = tk * 16;
         __syncthreads();
+        PHX_BEGIN(t_piv);
         if (B.tid < 256) {                                   // pivot block (identity-padded)
             const int r = B.tid & 15, c = B.tid >> 4, gi = k0 + r, gj = k0 + c;
             double v;
@@ -1377,6 +1387,8 @@ DEVNI int gm_spd_inverse_blocked(const Blk &B, const GmWork &W, int M)
             if (B.tid < 256) nD[(B.tid & 15) * 17 + (B.tid >> 4)] = nv;
             __syncthreads();
         }
+        PHX_END(t_piv, PH_INV_PIVOT);
+        PHX_BEGIN(t_tn);
         // Tn[i][r] = sum_s A(i, k0+s) * nD[s][r] for rows outside the block (zero inside / padding)
         for (int i = B.tid; i < Mp; i += B.nthr) {
             double lp[16];
@@ -1397,55 +1409,65 @@ DEVNI int gm_spd_inverse_blocked(const Blk &B, const GmWork &W, int M)
             }
         }
         __syncthreads();
+        PHX_END(t_tn, PH_INV_TN);
         // A22 += Tn * A21'  on the lower-triangle tiles that do not touch the pivot block.
         // MFMA rows <-> j (column of A), MFMA columns <-> i (row of A): stores are contiguous in i.
         // The tiles form a triangle over the nT - 1 non-pivot tile indices; tile number q = a (a + 1) / 2 + b
         // (b <= a) goes to wave q mod nwave.  Each wave handles INV_TT of its tiles per trip so that their loads
         // are in flight together (a tile on its own is one load -> matrix op -> store latency chain).
         {
-            const int n1 = nT - 1, n_tiles = n1 * (n1 + 1) / 2;
-            for (int q0 = B.wave; q0 < n_tiles; q0 += INV_TT * B.nwave) {
-                d4 acc[INV_TT];
-                double av[INV_TT][4], bv[INV_TT][4];
-                int ti2[INV_TT], tj2[INV_TT];
-                bool on[INV_TT];
-#pragma unroll
-                for (int z = 0; z < INV_TT; z++) {
-                    const int q = q0 + z * B.nwave;
-                    on[z] = q < n_tiles;
-                    const int qq = on[z] ? q : 0;
-                    int a = (int)((sqrt(8.0 * qq + 1.0) - 1.0) * 0.5);
-                    while ((a + 1) * (a + 2) / 2 <= qq) a++;
-                    while (a * (a + 1) / 2 > qq) a--;
-                    const int b = qq - a * (a + 1) / 2;
-                    ti2[z] = a < tk ? a : a + 1;                   // skip the pivot tile row / column
-                    tj2[z] = b < tk ? b : b + 1;
-                    const int jrow = tj2[z] * 16 + l15, icol = ti2[z] * 16 + l15;
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const int j = tj2[z] * 16 + l4 + 4 * r;
-                        acc[z][r] = (on[z] && icol < M && j < M) ? Sig[(size_t)j * ld + icol] : 0.0;
-                    }
+            // The work is cut into runs of up to INV_RUN tiles down one tile column b (same 16 columns j of A,
+            // consecutive row tiles a >= b): the A21' operand depends on b only and is loaded once per run, which
+            // takes a third off the bytes a tile moves -- this phase is bound by the CU's path to L2, not by the
+            // matrix cores.  Runs are dealt to the waves round-robin; INV_TT tiles of a run are in flight together.
+            const int n1 = nT - 1;
+            int cnt = 0;
+            for (int b = 0; b < n1; b++) {
+                const int tj = b < tk ? b : b + 1;                  // skip the pivot tile row / column
+                for (int a0 = b; a0 < n1; a0 += INV_RUN) {
+                    if ((cnt++) % B.nwave != B.wave) continue;
+                    const int a1 = a0 + INV_RUN < n1 ? a0 + INV_RUN : n1;
+                    const int jrow = tj * 16 + l15;
+                    double av[4];
 #pragma unroll
                     for (int kk = 0; kk < 4; kk++) {
                         const int kc = k0 + kk * 4 + l4;
                         double a_ = 0;
-                        if (on[z] && jrow < M && kc < M) a_ = (jrow > kc) ? Sig[(size_t)kc * ld + jrow] : Sig[(size_t)jrow * ld + kc];
-                        av[z][kk] = a_;
-                        bv[z][kk] = Tn[(size_t)icol * INV_TP + kk * 4 + l4];
+                        if (jrow < M && kc < M) a_ = (jrow > kc) ? Sig[(size_t)kc * ld + jrow] : Sig[(size_t)jrow * ld + kc];
+                        av[kk] = a_;
                     }
-                }
+                    for (int a = a0; a < a1; a += INV_TT) {
+                        d4 acc[INV_TT];
+                        double bv[INV_TT][4];
 #pragma unroll
-                for (int z = 0; z < INV_TT; z++)
+                        for (int z = 0; z < INV_TT; z++) {
+                            const int az = a + z < a1 ? a + z : a1 - 1;
+                            const int ti = az < tk ? az : az + 1;
+                            const int icol = ti * 16 + l15;
 #pragma unroll
-                    for (int kk = 0; kk < 4; kk++) acc[z] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[z][kk], bv[z][kk], acc[z], 0, 0, 0);
+                            for (int r = 0; r < 4; r++) {
+                                const int j = tj * 16 + l4 + 4 * r;
+                                acc[z][r] = (icol < M && j < M) ? Sig[(size_t)j * ld + icol] : 0.0;
+                            }
 #pragma unroll
-                for (int z = 0; z < INV_TT; z++) {
-                    const int icol = ti2[z] * 16 + l15;
+                            for (int kk = 0; kk < 4; kk++) bv[z][kk] = Tn[(size_t)icol * INV_TP + kk * 4 + l4];
+                        }
 #pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const int j = tj2[z] * 16 + l4 + 4 * r;
-                        if (on[z] && icol < M && j < M) Sig[(size_t)j * ld + icol] = acc[z][r];
+                        for (int z = 0; z < INV_TT; z++)
+#pragma unroll
+                            for (int kk = 0; kk < 4; kk++) acc[z] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[z][kk], acc[z], 0, 0, 0);
+#pragma unroll
+                        for (int z = 0; z < INV_TT; z++) {
+                            if (a + z < a1) {
+                                const int ti = a + z < tk ? a + z : a + z + 1;
+                                const int icol = ti * 16 + l15;
+#pragma unroll
+                                for (int r = 0; r < 4; r++) {
+                                    const int j = tj * 16 + l4 + 4 * r;
+                                    if (icol < M && j < M) Sig[(size_t)j * ld + icol] = acc[z][r];
+                                }
+                            }
+                        }
                     }
                 }
             }
@@ -1475,11 +1497,12 @@ DEVNI int gm_spd_inverse_blocked(const Blk &B, const GmWork &W, int M)
 }
 #endif
 
-DEV int gm_spd_inverse(const Blk &B, const GmWork &W, int M)
+DEV int gm_spd_inverse(const Blk &B, const GmWork &W, int M, long long *phx = nullptr)
 {
+    (void)phx;
 #ifndef PAREBEN_HOST_EMUL
     const int Mp = ((M + 15) >> 4) * 16;
-    if (M > 16 && Mp * INV_TP + 16 * 17 <= B.pool_n) return gm_spd_inverse_blocked(B, W, M);
+    if (M > 16 && Mp * INV_TP + 16 * 17 <= B.pool_n) return gm_spd_inverse_blocked(B, W, M, phx);
 #endif
     return gm_spd_inverse_scalar(B, W, M);
 }
@@ -1512,14 +1535,25 @@ DEVNI int gm_final_update(const Blk &B, const FoldDev &F, const GmWork &W, int K
         const gptr_cd G = as_global(F.G);
         const gptr_d H = as_global_rw(W.H), Sg = as_global_rw(W.Sig);
         for (int j = B.wave; j < M; j += B.nwave) {
-            const int uj = lu[j];
             const size_t rj = (size_t)lr[j] * K;
-            for (int i = B.lane; i < M; i += BLK_LANES) {
-                // Phi_i.Phi_j from the Gram matrix; one triangle so that H is exactly symmetric
-                double h = (i <= j ? G[(size_t)lr[i] * K + uj] : G[rj + lu[i]]) * beta;
-                if (i == j) h += la[i];
-                H[(size_t)j * ld + i] = h;
-                Sg[(size_t)j * ld + i] = h;
+            // Phi_i.Phi_j from the Gram matrix: element (j, i >= j) is read from Gram row j (one row per
+            // wave trip, not a column walk across M rows) and mirrored, so H is exactly symmetric.  Four
+            // gathers are issued before the first store so that they overlap.
+            for (int i0 = j + B.lane; i0 < M; i0 += 4 * BLK_LANES) {
+                double h[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) { const int i = i0 + c * BLK_LANES; h[c] = i < M ? G[rj + lu[i]] : 0.0; }
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const int i = i0 + c * BLK_LANES;
+                    if (i < M) {
+                        double v = h[c] * beta;
+                        if (i == j) v += la[i];
+                        H[(size_t)j * ld + i] = v;
+                        Sg[(size_t)j * ld + i] = v;
+                        if (i != j) { H[(size_t)i * ld + j] = v; Sg[(size_t)i * ld + j] = v; }
+                    }
+                }
             }
         }
         blk_sync(B);
@@ -1528,13 +1562,28 @@ DEVNI int gm_final_update(const Blk &B, const FoldDev &F, const GmWork &W, int K
 #endif
     PAR(l, M) W.v1[l] = W.bt[W.used[l]];
     blk_sync(B);
-    { PH_BEGIN(); const int bad = gm_spd_inverse(B, W, M); PH_END(PH_INVERSE); if (bad) return 1; }
+    { PH_BEGIN(); const int bad = gm_spd_inverse(B, W, M, S.ph); PH_END(PH_INVERSE); if (bad) return 1; }
     PH_BEGIN();
+#ifdef PAREBEN_HOST_EMUL
     PAR(i, M) {
         double a = 0;
         for (int j = 0; j < M; j++) a += W.v1[j] * W.Sig[(size_t)j * ld + i];
         W.mu[i] = a * beta;
     }
+#else
+    {   // the vector from LDS, Sigma through a global pointer: the row loads of a thread pipeline
+        const lptr_d lv = as_lds(B.pool);
+        PAR(j, M) lv[j] = W.v1[j];
+        blk_sync(B);
+        const gptr_cd Sg = as_global(W.Sig);
+        PAR(i, M) {
+            double a = 0;
+#pragma unroll 8
+            for (int j = 0; j < M; j++) a += lv[j] * Sg[(size_t)j * ld + i];
+            W.mu[i] = a * beta;
+        }
+    }
+#endif
     blk_sync(B);
     PH_END(PH_MU);
     return 0;

@@ -32,14 +32,14 @@ ph = np.fromfile(path, dtype=np.int64).reshape(-1, 16).astype(np.float64)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 np.savez(os.path.join(ROOT, "gpurun_out", "phase_dump.npz"), ph=ph, cnt=cnt, alpha=alpha, lam=lam)
 names = ["fullstat_features", "fullstat_rest(incl in total only)", "delta_ml+collect", "actions", "noise", "spd_inverse", "action_ksweep", "total",
-         "act_matvec", "act_rank1", "act_refresh", "h_build", "mu_after_inv", "batch_track", "sse", "-"]
+         "act_matvec", "act_rank1", "act_refresh", "h_build", "mu_after_inv", "batch_track", "inv_pivot", "inv_tn"]
 tot = ph[:, 7].sum()
 print("sum of per-fit wall ticks (100 MHz): %.3f s over %d fits" % (tot / 1e8, len(ph)))
 cc = cnt.reshape(-1, 12).astype(np.float64)
 print("aggregate full-stat rate per CU: %.1f GFLOP/s (peak 307); action Gram-row rate per CU: %.1f GB/s" % (
     2.0 * a.p * cc[:, 8].sum() / (ph[:, 0].sum() / 1e8) / 1e9, 8.0 * a.p * cc[:, 6].sum() / (ph[:, 3].sum() / 1e8) / 1e9))
 print("shader clock during the full-stat pass: %.0f MHz" % (ph[:, 1].sum() / ph[:, 0].sum() * 100.0))
-for k in (0, 2, 3, 6, 8, 9, 10, 13, 4, 5, 11, 12):
+for k in (0, 2, 3, 6, 8, 9, 10, 13, 4, 5, 14, 15, 11, 12):
     print("  %-22s %6.2f %%" % (names[k], 100 * ph[:, k].sum() / tot))
 print("  %-22s %6.2f %%" % ("other", 100 * (tot - ph[:, [0, 2, 3, 4, 5, 11, 12]].sum()) / tot))
 heavy = np.argsort(ph[:, 7])[-5:]
@@ -47,4 +47,4 @@ for u in heavy:
     c = cnt.reshape(-1, 12)[u]
     fs_s = ph[u, 0] / 1e8
     print("  fit %d: %.3f s  M=%d inner=%d adds=%d fullstat=%d sumM2=%.3g fs_rate=%.1f GF/s act_GBs=%.1f | " % (u, ph[u, 7] / 1e8, c[9], c[1], c[2], c[5], c[8], 2.0 * a.p * c[8] / fs_s / 1e9, 8.0 * a.p * c[6] / (ph[u, 3] / 1e8) / 1e9),
-          " ".join("%s=%.0f%%" % (names[k][:8], 100 * ph[u, k] / ph[u, 7]) for k in (0, 2, 3, 6, 8, 9, 10, 13, 4, 5, 11, 12)))
+          " ".join("%s=%.0f%%" % (names[k][:8], 100 * ph[u, k] / ph[u, 7]) for k in (0, 2, 3, 6, 8, 9, 10, 13, 4, 5, 14, 15, 11, 12)))
