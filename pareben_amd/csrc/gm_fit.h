@@ -50,7 +50,8 @@ enum { UP_FREE = -1, UP_LOST = -2 };
 #define PHX_END(v, k) do {} while (0)
 #endif
 enum { PH_FS_FEAT = 0, PH_FS_REST = 1, PH_DML = 2, PH_ACTION = 3, PH_NOISE = 4, PH_INVERSE = 5, PH_KSWEEP = 6, PH_TOTAL = 7,
-       PH_MATVEC = 8, PH_RANK1 = 9, PH_REFRESH = 10, PH_HBUILD = 11, PH_MU = 12, PH_TRACK = 13, PH_INV_PIVOT = 14, PH_INV_TN = 15, PH_N = 16 };
+       PH_MATVEC = 8, PH_RANK1 = 9, PH_REFRESH = 10, PH_HBUILD = 11, PH_MU = 12, PH_TRACK = 13, PH_INV_PIVOT = 14, PH_INV_TN = 15,
+       PH_FS_MINE = 16, PH_FS_CHUNKS = 17, PH_SQ_MINE = 18, PH_SQ_CHUNKS = 19, PH_FS_WAIT = 20, PH_SQ_WAIT = 21, PH_N = 24 };
 
 struct GmScalars {
     GmVariant v;       // main-effect / epistasis rule set
@@ -390,7 +391,9 @@ DEVNI void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W,
 #define AT_STORE(p, v) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define AT_ADD(p, v) __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 DEV bool fs_epoch_open(unsigned long long w) { return (w >> 32) & 1; }
-DEV int job_chunk(int kind) { return kind == JOB_SQ ? SQ_CHUNK : FS_CHUNK; }
+// tiles per claim: a full-stat tile of a large active set is long enough (0.1 ms and up) to be claimed on its own,
+// which is what lets a whole idle GPU work on the one heavy fit left on it
+DEV int job_chunk(int kind, int M) { return kind != JOB_FULLSTAT ? SQ_CHUNK : FS_CHUNK; }
 // thread 0 only: first tile of the claimed chunk, or -1 when the job is closed / fully handed out
 DEV int fs_claim(FsJob *job, int n_tiles, int chunk)
 {
@@ -408,7 +411,7 @@ DEV bool job_share(const Blk &B, GmScalars &S, int kind, int M, int n_tiles, dou
                    double c2, Work work)
 {
     const FsShare *sh = S.share;
-    const int chunk = job_chunk(kind);
+    const int chunk = job_chunk(kind, M);
     if (!(sh && sh->jobs) || n_tiles < 4 * chunk) return false;
     __syncthreads();
     // somebody may be free to help: always in the tail; from the start when the launch is small or the fit is a
@@ -447,7 +450,15 @@ DEV bool job_share(const Blk &B, GmScalars &S, int kind, int M, int n_tiles, dou
         const int total = (n_tiles + chunk - 1) / chunk;
         AT_ADD(&job->done, mine);
         long spins = 0;
+#ifdef PAREBEN_PHASE_TIMERS
+        const long long tw0 = (long long)wall_clock64();
+#endif
         while (AT_LOAD(&job->done) < total && spins < 200000000L) { __builtin_amdgcn_s_sleep(4); spins++; }
+#ifdef PAREBEN_PHASE_TIMERS
+        const int fsj = kind == JOB_FULLSTAT;
+        S.ph[fsj ? PH_FS_MINE : PH_SQ_MINE] += mine; S.ph[fsj ? PH_FS_CHUNKS : PH_SQ_CHUNKS] += total;
+        S.ph[fsj ? PH_FS_WAIT : PH_SQ_WAIT] += (long long)wall_clock64() - tw0;
+#endif
         B.ired[0] = AT_LOAD(&job->done) >= total;
         const unsigned long long w = AT_LOAD(&job->word);
         AT_STORE(&job->word, ((w >> 32) + 1) << 32);           // even epoch: closed
@@ -756,17 +767,32 @@ DEV void gm_rank1(const Blk &B, const GmWork &W, int M, double *scr, FA fa, FB f
     blk_sync(B);
     const gptr_d Sg = as_global_rw(W.Sig);
     const int lane = B.lane, wave = B.wave, nwave = B.nwave;
-    for (int i0 = 0; i0 < M; i0 += 4 * BLK_LANES) {
-        double br[4];
+    // up to 8 column chunks of 64 per pass (balanced over the passes), two rows per trip: 16 loads in flight
+    const int NC = (M + BLK_LANES - 1) / BLK_LANES, npass = (NC + 7) >> 3, cpp = (NC + npass - 1) / npass;
+    for (int p = 0; p < npass; p++) {
+        const int i0 = p * cpp * BLK_LANES + lane;
+        double br[8];
 #pragma unroll
-        for (int c = 0; c < 4; c++) { const int i = i0 + c * BLK_LANES + lane; br[c] = i < M ? lb[i] : 0.0; }
-        for (int j = wave; j < M; j += nwave) {
-            const double f = la[j];
-            double sv[4];
+        for (int c = 0; c < 8; c++) { const int i = i0 + c * BLK_LANES; br[c] = (c < cpp && i < M) ? lb[i] : 0.0; }
+        for (int j = wave; j < M; j += 2 * nwave) {
+            const int j2 = j + nwave;
+            const bool two = j2 < M;
+            const double f0 = la[j], f1 = two ? la[j2] : 0.0;
+            double s0[8], s1[8];
 #pragma unroll
-            for (int c = 0; c < 4; c++) { const int i = i0 + c * BLK_LANES + lane; sv[c] = i < M ? Sg[(size_t)j * ld + i] : 0.0; }
+            for (int c = 0; c < 8; c++) {
+                const int i = i0 + c * BLK_LANES;
+                const bool on = c < cpp && i < M;
+                s0[c] = on ? Sg[(size_t)j * ld + i] : 0.0;
+                s1[c] = (on && two) ? Sg[(size_t)j2 * ld + i] : 0.0;
+            }
 #pragma unroll
-            for (int c = 0; c < 4; c++) { const int i = i0 + c * BLK_LANES + lane; if (i < M) Sg[(size_t)j * ld + i] = sv[c] + f * br[c]; }
+            for (int c = 0; c < 8; c++) {
+                const int i = i0 + c * BLK_LANES;
+                const bool on = c < cpp && i < M;
+                if (on) Sg[(size_t)j * ld + i] = s0[c] + f0 * br[c];
+                if (on && two) Sg[(size_t)j2 * ld + i] = s1[c] + f1 * br[c];
+            }
         }
     }
 #endif
@@ -1112,7 +1138,7 @@ DEV void gm_add_apply(double &sin, double &qin, double beta, double rowval, doub
 // loads each row element once and feeds TT accumulators; the new features' own rows (the rows M0 .. M0+T-1
 // of the sweep) are picked up on the way.  Then the T updates are applied in order.  TT = T rounded up.
 template <int TT>
-DEV void gm_sq_batch(const Blk &B, const FoldDev &F, const GmWork &W, int K, int M0, int T, double beta)
+DEV void gm_sq_batch(const Blk &B, const FoldDev &F, const GmWork &W, int K, int M0, int T, double beta, int f0, int f1)
 {
     typedef double d2 __attribute__((ext_vector_type(2), aligned(8)));
     typedef const d2 __attribute__((address_space(1))) *gptr_cd2;
@@ -1132,8 +1158,8 @@ DEV void gm_sq_batch(const Blk &B, const FoldDev &F, const GmWork &W, int K, int
     for (int j = tid; j < Mt; j += nthr) lused[j] = W.rowid[j];
     blk_sync(B);
     K = uni(K);
-    const int Kp = K & ~1;
-    for (int ib = 0; ib < Kp; ib += 2 * nthr) {
+    const int Kp = f1;                                          // features [f0, f1), both even, f1 <= K & ~1
+    for (int ib = f0; ib < Kp; ib += 2 * nthr) {
         const int i = ib + 2 * tid;
         const unsigned off = (unsigned)((i < Kp ? i : Kp - 2) * 8);
         d2 acc[TT], rowv[TT];
@@ -1172,13 +1198,34 @@ DEV void gm_sq_batch(const Blk &B, const FoldDev &F, const GmWork &W, int K, int
             W.Sin[i] = s0; W.Qin[i] = q0; W.Sin[i + 1] = s1; W.Qin[i + 1] = q1;
         }
     }
-    if ((K & 1) && tid == 0) {                                  // the odd last feature
-        const int i = K - 1;
+    blk_sync(B);
+}
+
+// features [f0, f1) of the sweep of a run of T adds (the owner's whole range, or a claimed chunk of it)
+DEV void gm_sq_batch_range(const Blk &B, const FoldDev &F, const GmWork &W, int K, int M0, int T, double beta, int f0, int f1)
+{
+    if (T <= 4) gm_sq_batch<4>(B, F, W, K, M0, T, beta, f0, f1);
+    else if (T <= 8) gm_sq_batch<8>(B, F, W, K, M0, T, beta, f0, f1);
+    else gm_sq_batch<ADD_TB>(B, F, W, K, M0, T, beta, f0, f1);
+}
+
+// the whole sweep: shared with idle workgroups when the job board is open (same arithmetic per feature
+// whoever runs it), the odd last feature by the owner
+DEVNI void gm_sq_batch_all(const Blk &B, const FoldDev &F, const GmWork &W, int K, int M0, int T, double beta, GmScalars &S)
+{
+    const int Kp = K & ~1;
+    const int n_tiles = (Kp + FS_FT - 1) / FS_FT;
+    const bool shared = M0 + T >= 96 && job_share(B, S, JOB_SQB, M0, n_tiles, beta, T, -1, 0.0, 0.0, [&](int t0, int t1) {
+        gm_sq_batch_range(B, F, W, K, M0, T, beta, t0 * FS_FT, t1 * FS_FT < Kp ? t1 * FS_FT : Kp);
+    });
+    if (!shared) gm_sq_batch_range(B, F, W, K, M0, T, beta, 0, Kp);
+    if ((K & 1) && B.tid == 0) {                                // the odd last feature
+        const int i = K - 1, ldv = W.cap + 2;
         double s0 = W.Sin[i], q0 = W.Qin[i];
         for (int t = 0; t < T; t++) {
             double a = 0;
-            for (int j = 0; j < M0 + t; j++) a += *(gptr_cd)(G + ((size_t)lused[j] * (size_t)K + i) * 8) * lvb[t * Mt + j];
-            gm_add_apply(s0, q0, beta, *(gptr_cd)(G + ((size_t)lused[M0 + t] * (size_t)K + i) * 8), a, lsc[t], lsc[TT + t]);
+            for (int j = 0; j < M0 + t; j++) a += F.G[(size_t)W.rowid[j] * K + i] * W.vb[(size_t)t * ldv + j];
+            gm_add_apply(s0, q0, beta, F.G[(size_t)W.rowid[M0 + t] * K + i], a, W.bsc[t], W.bsc[ADD_TB + t]);
         }
         W.Sin[i] = s0; W.Qin[i] = q0;
     }
@@ -1259,9 +1306,7 @@ DEVNI void gm_add_batch(const Blk &B, const FoldDev &F, const GmWork &W, int K, 
         blk_sync(B);
     }
     PH_BEGIN();
-    if (T <= 4) gm_sq_batch<4>(B, F, W, K, M0, T, beta);
-    else if (T <= 8) gm_sq_batch<8>(B, F, W, K, M0, T, beta);
-    else gm_sq_batch<ADD_TB>(B, F, W, K, M0, T, beta);
+    gm_sq_batch_all(B, F, W, K, M0, T, beta, S);
     PH_END(PH_KSWEEP);
     S.M = M0 + T;
 }

@@ -347,7 +347,7 @@ __device__ void fs_help_loop(const Blk &B, const FsShare &sh, int K, bool until_
                 const int b = base + B.lane;
                 unsigned long long w = b < sh.n_blocks ? AT_LOAD(&sh.jobs[b].word) : 0ull;
                 const int nt = (b < sh.n_blocks && fs_epoch_open(w)) ? AT_LOAD(&sh.jobs[b].n_tiles) : 0;
-                const int chunk = (b < sh.n_blocks && fs_epoch_open(w)) ? job_chunk(AT_LOAD(&sh.jobs[b].kind)) : FS_CHUNK;
+                const int chunk = (b < sh.n_blocks && fs_epoch_open(w)) ? job_chunk(AT_LOAD(&sh.jobs[b].kind), AT_LOAD(&sh.jobs[b].M)) : FS_CHUNK;
                 unsigned long long cand = __ballot(fs_epoch_open(w) && (int)(unsigned)w < nt);
                 while (cand && owner < 0) {
                     const int l = __ffsll((long long)cand) - 1;
@@ -385,8 +385,11 @@ __device__ void fs_help_loop(const Blk &B, const FsShare &sh, int K, bool until_
         const double c2 = __hip_atomic_load(&job->c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const GmWork Wo = ws_carve(sh.ws + (size_t)owner * sh.ws_stride, K, sh.cap, sh.offK, sh.offSig, sh.offM);
         const FoldDev Fo = sh.folds[fold];
-        const int last = first + job_chunk(kind) < n_tiles ? first + job_chunk(kind) : n_tiles;
-        if (kind == JOB_SQ)
+        const int last = first + job_chunk(kind, M) < n_tiles ? first + job_chunk(kind, M) : n_tiles;
+        if (kind == JOB_SQB) {
+            const int Kp = K & ~1;
+            gm_sq_batch_range(B, Fo, Wo, K, M, mode, beta, first * FS_FT, last * FS_FT < Kp ? last * FS_FT : Kp);
+        } else if (kind == JOB_SQ)
             gm_sq_tiles(B, Fo, Wo, K, M, Wo.v2, mode, beta, c1, c2, rid >= 0 ? Fo.G + (size_t)rid * K : nullptr, first, last, true);
         else
             gm_fullstat_features(B, Fo, Wo, K, M, beta, first, last);

@@ -79,7 +79,7 @@ struct FsJob {
     int pad;
     double beta, c1, c2;   // one 64-byte line per job
 };
-enum { JOB_FULLSTAT = 0, JOB_SQ = 1 };
+enum { JOB_FULLSTAT = 0, JOB_SQ = 1, JOB_SQB = 2 };   // JOB_SQB: the sweep of a run of adds (M = size before the run, mode = run length)
 struct FsShare {           // null jobs = sharing off
     FsJob *jobs;           // one per workgroup of the launch
     int *active;           // workgroups that currently own a fit
