@@ -110,17 +110,21 @@ template <class T> DEV T *uni_ptr(T *p)
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return (T *)(((unsigned long long)hi << 32) | lo);
 }
-#define FS_TPP 16          // row tiles of Sigma per pass (16 x 16 rows = 256 active features)
+#ifndef FS_NB
+#define FS_NB 2            // 16-feature column blocks per wave: every Sigma panel read from LDS feeds FS_NB matrix ops
+#endif
+#define FS_TPP (16 / FS_NB) // row tiles of Sigma per pass (FS_NB x FS_TPP accumulator tiles per wave)
 #define FS_PC 16           // Gram rows staged per step (= one k-block)
 #ifndef FS_NWAVES
 #define FS_NWAVES 8        // wavefronts per fit workgroup (set by the kernel file from FIT_THREADS)
 #endif
-#define FS_FT (16 * FS_NWAVES)   // features per tile: every wave owns one 16-feature column block of it
+#define FS_FT (16 * FS_NWAVES * FS_NB)   // features per tile: every wave owns FS_NB 16-feature column blocks of it
+#define SQ_FT 128          // feature tile of the shared action mat-vecs (job board granularity)
 #define FS_NH (FS_FT / 64)       // 64-lane pieces of a staged Gram row
 #define FS_LD (FS_FT + 16)       // LDS row pitch of the Gram block in doubles (conflict-free b64 reads)
 #define FS_RPW (16 / FS_NWAVES)  // Gram rows each wave stages per step
 #define FS_PPW (FS_TPP / FS_NWAVES)   // Sigma panels each wave stages per step
-static_assert(16 % FS_NWAVES == 0 && FS_TPP % FS_NWAVES == 0 && FS_FT % 64 == 0, "full-stat tiling");
+static_assert(16 % FS_NWAVES == 0 && FS_TPP % FS_NWAVES == 0 && FS_FT % 64 == 0 && 16 % FS_NB == 0, "full-stat tiling");
 
 // The full-stat pass is ONE software pipeline over all (feature tile, pass, k-block) steps of a call:
 // a cursor names the step; what a step needs from memory is requested two steps ahead and written to
@@ -162,7 +166,8 @@ DEV void fs_advance(FsCur &c, int n_pass, int nJ, int tpp)
 template <int CUR>
 DEV void fs_step(gptr_cc Sig, gptr_cc G, lptr_i lused, lptr_d lmu, lptr_d bcur, lptr_d bnxt, lptr_d acur, lptr_d anxt,
                  int ld, const FsCur &c0, const FsCur &c1, const FsCur &c2, int tpp, int nJ, int M, int K, int wave, int lane,
-                 double (&pa)[2][FS_PPW][4], double (&sv)[2][FS_RPW][FS_NH], d4 (&acc)[FS_TPP], double &qsum, double &msum)
+                 double (&pa)[2][FS_PPW][4], double (&sv)[2][FS_RPW][FS_NH], d4 (&acc)[FS_NB][FS_TPP], double (&qsum)[FS_NB],
+                 double (&msum)[FS_NB])
 {
     constexpr int NX = CUR ^ 1;
     const int l15 = lane & 15, l4 = lane >> 4;
@@ -194,24 +199,34 @@ DEV void fs_step(gptr_cc Sig, gptr_cc G, lptr_i lused, lptr_d lmu, lptr_d bcur, 
     }
     // ---- matrix ops of step g
     const int jb = c0.pass * tpp;
-    double bv[4];
+    double bv[FS_NB][4];                                      // column block nb of this wave: features 16 (wave + nb FS_NWAVES) ..
 #pragma unroll
-    for (int s = 0; s < 4; s++) bv[s] = bcur[(4 * s + l4) * FS_LD + 16 * wave + l15];
+    for (int nb = 0; nb < FS_NB; nb++)
+#pragma unroll
+        for (int s = 0; s < 4; s++) bv[nb][s] = bcur[(4 * s + l4) * FS_LD + 16 * (wave + nb * FS_NWAVES) + l15];
 #pragma unroll
     for (int t = 0; t < FS_TPP; t++) {
         const int J = jb + t;
         if (t < tpp && J < nJ && c0.h <= J) {
 #pragma unroll
-            for (int s = 0; s < 4; s++)
-                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(acur[(t * 4 + s) * 64 + lane], bv[s], acc[t], 0, 0, 0);
+            for (int s = 0; s < 4; s++) {
+                const double a = acur[(t * 4 + s) * 64 + lane];
+#pragma unroll
+                for (int nb = 0; nb < FS_NB; nb++) acc[nb][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[nb][s], acc[nb][t], 0, 0, 0);
+            }
             if (c0.h == J) {                                  // tile J is complete: fold and clear
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const double bj = bcur[(l4 + 4 * r) * FS_LD + 16 * wave + l15];
-                    qsum += acc[t][r] * bj;
-                    msum += bj * lmu[c0.h * 16 + l4 + 4 * r];
+                    const double mj = lmu[c0.h * 16 + l4 + 4 * r];
+#pragma unroll
+                    for (int nb = 0; nb < FS_NB; nb++) {
+                        const double bj = bcur[(l4 + 4 * r) * FS_LD + 16 * (wave + nb * FS_NWAVES) + l15];
+                        qsum[nb] += acc[nb][t][r] * bj;
+                        msum[nb] += bj * mj;
+                    }
                 }
-                acc[t] = d4{0, 0, 0, 0};
+#pragma unroll
+                for (int nb = 0; nb < FS_NB; nb++) acc[nb][t] = d4{0, 0, 0, 0};
             }
         }
     }
@@ -297,11 +312,15 @@ DEVNI void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W,
     c0.i0 = i_begin; c0.pass = 0; c0.h = 0; c0.last = (tpp < nJ ? tpp : nJ) - 1;
     c1 = c0; fs_advance(c1, n_pass, nJ, tpp);
     c2 = c1; fs_advance(c2, n_pass, nJ, tpp);
-    d4 acc[FS_TPP];
+    d4 acc[FS_NB][FS_TPP];
 #pragma unroll
-    for (int t = 0; t < FS_TPP; t++) acc[t] = d4{0, 0, 0, 0};
+    for (int nb = 0; nb < FS_NB; nb++)
+#pragma unroll
+        for (int t = 0; t < FS_TPP; t++) acc[nb][t] = d4{0, 0, 0, 0};
     double pa[2][FS_PPW][4], sv[2][FS_RPW][FS_NH];
-    double qsum = 0, msum = 0;
+    double qsum[FS_NB], msum[FS_NB];
+#pragma unroll
+    for (int nb = 0; nb < FS_NB; nb++) { qsum[nb] = 0; msum[nb] = 0; }
     {   // pipeline fill: step 0's operands straight to LDS buffers 0, step 1's into ring slot 1
         const unsigned lane_off = (unsigned)((l4 * ld + l15) * 8);
 #pragma unroll
@@ -339,12 +358,14 @@ DEVNI void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W,
     // the four row groups of the accumulator layout: two xor-shuffles, then lanes 0..15 write them.
 #define FS_FINISH_TILE(cc)                                                                                           \
         if ((cc).h == (cc).last && (cc).pass == n_pass - 1) {                                                        \
-            double q = qsum, m = msum;                                                                               \
-            q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);                                                  \
-            m += __shfl_xor(m, 16, 64); m += __shfl_xor(m, 32, 64);                                                  \
-            const int i = (cc).i0 + 16 * wave + l15;                                                                 \
-            if (lane < 16 && i < K) { gSin[i] = beta - beta * q * beta; gQin[i] = beta * (gbt[i] - m); }             \
-            qsum = 0; msum = 0;                                                                                      \
+            _Pragma("unroll") for (int nb = 0; nb < FS_NB; nb++) {                                                   \
+                double q = qsum[nb], m = msum[nb];                                                                   \
+                q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);                                              \
+                m += __shfl_xor(m, 16, 64); m += __shfl_xor(m, 32, 64);                                              \
+                const int i = (cc).i0 + 16 * (wave + nb * FS_NWAVES) + l15;                                          \
+                if (lane < 16 && i < K) { gSin[i] = beta - beta * q * beta; gQin[i] = beta * (gbt[i] - m); }         \
+                qsum[nb] = 0; msum[nb] = 0;                                                                          \
+            }                                                                                                        \
         }
 #define FS_STEP(CURSLOT, gg)                                                                                         \
         {                                                                                                            \
@@ -385,7 +406,7 @@ DEVNI void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W,
 // agent-scope acquire + s_waitcnt vmcnt(0) + barrier before plain loads.  Nobody waits while holding
 // a chunk, so every wait ends; the owner's wait is bounded anyway and flags the fit if it expires.
 #ifndef PAREBEN_HOST_EMUL
-#define FS_CHUNK 4         // tiles per claim, full-stat pass
+#define FS_CHUNK (4 / FS_NB) // tiles per claim, full-stat pass (512 features)
 #define SQ_CHUNK 8         // tiles per claim, action mat-vec (1024 features = one pair per thread)
 #define AT_LOAD(p) __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define AT_STORE(p, v) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
@@ -702,7 +723,7 @@ DEV void gm_sq_tiles(const Blk &B, const FoldDev &F, const GmWork &W, int K, int
         for (int j = tid; j < M; j += nthr) { lvec[j] = vec[j]; lused[j] = W.rowid[j]; }
         blk_sync(B);
     }
-    const int Kp = K & ~1, f0 = t0 * FS_FT, f1 = t1 * FS_FT < Kp ? t1 * FS_FT : Kp;
+    const int Kp = K & ~1, f0 = t0 * SQ_FT, f1 = t1 * SQ_FT < Kp ? t1 * SQ_FT : Kp;
     gm_sq_core<1, 8>(G, lvec, lused, W, uni(K), uni(M), mode, beta, c1, c2, newrow, f0, f1, tid, nthr);
 }
 #endif
@@ -731,7 +752,7 @@ DEVNI void gm_sq_update(const Blk &B, const FoldDev &F, const GmWork &W, int K, 
     for (int j = tid; j < M; j += nthr) { lvec[j] = vec[j]; lused[j] = W.rowid[j]; }
     blk_sync(B);
     const int Kp = K & ~1;                                    // pairs cover [0, Kp); an odd last feature is handled below
-    const int n_tiles = (Kp + FS_FT - 1) / FS_FT;
+    const int n_tiles = (Kp + SQ_FT - 1) / SQ_FT;
     const bool shared = M >= 96 && job_share(B, S, JOB_SQ, M, n_tiles, beta, mode, rid, c1, c2, [&](int t0, int t1) {
         gm_sq_tiles(B, F, W, K, M, vec, mode, beta, c1, c2, newrow, t0, t1, false);
     });
@@ -1214,9 +1235,9 @@ DEV void gm_sq_batch_range(const Blk &B, const FoldDev &F, const GmWork &W, int 
 DEVNI void gm_sq_batch_all(const Blk &B, const FoldDev &F, const GmWork &W, int K, int M0, int T, double beta, GmScalars &S)
 {
     const int Kp = K & ~1;
-    const int n_tiles = (Kp + FS_FT - 1) / FS_FT;
+    const int n_tiles = (Kp + SQ_FT - 1) / SQ_FT;
     const bool shared = M0 + T >= 96 && job_share(B, S, JOB_SQB, M0, n_tiles, beta, T, -1, 0.0, 0.0, [&](int t0, int t1) {
-        gm_sq_batch_range(B, F, W, K, M0, T, beta, t0 * FS_FT, t1 * FS_FT < Kp ? t1 * FS_FT : Kp);
+        gm_sq_batch_range(B, F, W, K, M0, T, beta, t0 * SQ_FT, t1 * SQ_FT < Kp ? t1 * SQ_FT : Kp);
     });
     if (!shared) gm_sq_batch_range(B, F, W, K, M0, T, beta, 0, Kp);
     if ((K & 1) && B.tid == 0) {                                // the odd last feature

@@ -388,7 +388,7 @@ __device__ void fs_help_loop(const Blk &B, const FsShare &sh, int K, bool until_
         const int last = first + job_chunk(kind, M) < n_tiles ? first + job_chunk(kind, M) : n_tiles;
         if (kind == JOB_SQB) {
             const int Kp = K & ~1;
-            gm_sq_batch_range(B, Fo, Wo, K, M, mode, beta, first * FS_FT, last * FS_FT < Kp ? last * FS_FT : Kp);
+            gm_sq_batch_range(B, Fo, Wo, K, M, mode, beta, first * SQ_FT, last * SQ_FT < Kp ? last * SQ_FT : Kp);
         } else if (kind == JOB_SQ)
             gm_sq_tiles(B, Fo, Wo, K, M, Wo.v2, mode, beta, c1, c2, rid >= 0 ? Fo.G + (size_t)rid * K : nullptr, first, last, true);
         else
