@@ -110,6 +110,9 @@ template <class T> DEV T *uni_ptr(T *p)
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return (T *)(((unsigned long long)hi << 32) | lo);
 }
+#ifndef FS_DIRECT_B
+#define FS_DIRECT_B 1      // Gram operand of the full-stat pass straight from memory (0: staged through LDS)
+#endif
 #ifndef FS_NB
 #define FS_NB 2            // 16-feature column blocks per wave: every Sigma panel read from LDS feeds FS_NB matrix ops
 #endif
@@ -256,6 +259,93 @@ DEV void fs_step(gptr_cc Sig, gptr_cc G, lptr_i lused, lptr_d lmu, lptr_d bcur, 
         }
     }
 }
+
+// The same step with the Gram operand taken straight from memory (FS_DIRECT_B): lane l of the B operand of
+// k-group s holds G[row 16 h + 4 s + (l >> 4)][feature 16 blk + (l & 15)] -- 16 consecutive features of one Gram
+// row per 16 lanes, i.e. whole 128-byte lines -- and a wave needs only its own column blocks, so nothing about
+// the Gram block has to be shared through LDS: each wave loads its operands for step g+1 into a register ring
+// during step g.  The rows a lane holds as B operand (4 s + l4) are exactly the rows of its accumulator
+// registers (l4 + 4 r), so the fold on the diagonal uses the operand registers as b_j.  Only the Sigma panels
+// (identical for all waves) still go through LDS.  loff[p] = byte offset of Gram row p of the active set.
+typedef const unsigned long long __attribute__((address_space(3))) *lptr_cull;
+template <int CUR>
+DEV void fs_step_d(gptr_cc Sig, gptr_cc G, lptr_cull loff, lptr_d lmu, lptr_d acur, lptr_d anxt,
+                   int ld, const FsCur &c0, const FsCur &c1, const FsCur &c2, int tpp, int nJ, int M, int K, int wave, int lane,
+                   double (&pa)[2][FS_PPW][4], double (&bvr)[2][FS_NB][4], d4 (&acc)[FS_NB][FS_TPP], double (&qsum)[FS_NB],
+                   double (&msum)[FS_NB])
+{
+    constexpr int NX = CUR ^ 1;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    // ---- requests: this wave's share of the Sigma panels of step g+2 ...
+    {
+        const unsigned lane_off = (unsigned)((l4 * ld + l15) * 8);
+#pragma unroll
+        for (int pi = 0; pi < FS_PPW; pi++) {
+            const int t2 = wave + pi * FS_NWAVES, J = c2.pass * tpp + t2;
+            const bool on = t2 < tpp && J < nJ && c2.h <= J;
+            const unsigned o = on ? (unsigned)((c2.h * 16 * ld + J * 16) * 8) + lane_off : 0u;
+            const unsigned st = on ? (unsigned)(4 * ld * 8) : 0u;
+#pragma unroll
+            for (int s = 0; s < 4; s++) pa[CUR][pi][s] = *(gptr_cd)(Sig + (o + s * st));
+        }
+    }
+    // ... and its own Gram operands of step g+1
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const unsigned long long ro = loff[c1.h * 16 + 4 * s + l4];
+#pragma unroll
+        for (int nb = 0; nb < FS_NB; nb++) {
+            const int i = c1.i0 + 16 * (wave + nb * FS_NWAVES) + l15;
+            bvr[NX][nb][s] = *(gptr_cd)(G + (ro + (unsigned)((i < K ? i : K - 1) * 8)));
+        }
+    }
+    // ---- matrix ops of step g; rows beyond the active set contribute zero
+    const int jb = c0.pass * tpp;
+    double bv[FS_NB][4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const bool live = c0.h * 16 + 4 * s + l4 < M;
+#pragma unroll
+        for (int nb = 0; nb < FS_NB; nb++) bv[nb][s] = live ? bvr[CUR][nb][s] : 0.0;
+    }
+#pragma unroll
+    for (int t = 0; t < FS_TPP; t++) {
+        const int J = jb + t;
+        if (t < tpp && J < nJ && c0.h <= J) {
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const double a = acur[(t * 4 + s) * 64 + lane];
+#pragma unroll
+                for (int nb = 0; nb < FS_NB; nb++) acc[nb][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[nb][s], acc[nb][t], 0, 0, 0);
+            }
+            if (c0.h == J) {                                  // tile J is complete: fold and clear
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const double mj = lmu[c0.h * 16 + l4 + 4 * r];
+#pragma unroll
+                    for (int nb = 0; nb < FS_NB; nb++) {
+                        qsum[nb] += acc[nb][t][r] * bv[nb][r];
+                        msum[nb] += bv[nb][r] * mj;
+                    }
+                }
+#pragma unroll
+                for (int nb = 0; nb < FS_NB; nb++) acc[nb][t] = d4{0, 0, 0, 0};
+            }
+        }
+    }
+    // ---- step g+1's Sigma panels (requested during step g-1) -> the other LDS buffer
+#pragma unroll
+    for (int pi = 0; pi < FS_PPW; pi++) {
+        const int t = wave + pi * FS_NWAVES, J = c1.pass * tpp + t;
+        const double w = c1.h < J ? 2.0 : 1.0;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            double v = pa[NX][pi][s] * w;
+            asm volatile("" : "+v"(v));                        // consume the load on every path (see fs_step)
+            if (t < tpp && J < nJ && c1.h <= J) anxt[(t * 4 + s) * 64 + lane] = v;
+        }
+    }
+}
 #endif
 
 // S_in[i] = beta - beta^2 b_i' Sigma b_i,  Q_in[i] = beta (bt_i - b_i' mu)  for every feature,
@@ -280,6 +370,110 @@ DEVNI void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W,
         W.Sin[i] = beta - beta * quad * beta;
         W.Qin[i] = beta * (W.bt[i] - bm);
     }
+#else
+#if FS_DIRECT_B
+    // see fs_step_d.  B lives in memory (reference argument of a non-inlined function): take register
+    // copies once, or every use in the loop becomes a flat load followed by s_waitcnt vmcnt(0); results
+    // leave through global-address-space pointers for the same reason.
+    const int lane = B.lane, wave = uni(B.wave), tid = B.tid, nthr = uni(B.nthr);
+    const gptr_cc Sig = (gptr_cc)as_global(uni_ptr(W.Sig));
+    const gptr_cc G = (gptr_cc)as_global(uni_ptr(F.G));
+    const gptr_d gSin = as_global_rw(uni_ptr(W.Sin)), gQin = as_global_rw(uni_ptr(W.Qin));
+    const gptr_cd gbt = as_global(uni_ptr(W.bt));
+    double *pool = uni_ptr(B.pool);
+    const lptr_d la = as_lds(pool);                                         // 2 x FS_TPP x 256 staged Sigma panels
+    unsigned long long *loff_w = (unsigned long long *)(pool + 2 * FS_TPP * 256);          // Gram row byte offsets, M <= 1024
+    const lptr_cull loff = (lptr_cull)loff_w;
+    const lptr_d lmu = as_lds(pool + 2 * FS_TPP * 256 + 1024);              // mu, zero-padded to a k-block
+    K = uni(K); M = uni(M);
+    const int ld = uni(W.ld);
+    const int nJ = (M + 15) >> 4;
+    const int n_pass = (nJ + FS_TPP - 1) / FS_TPP;
+    const int tpp = (nJ + n_pass - 1) / n_pass;       // row tiles per pass, balanced: 19 tiles run as 7 + 6 + 6, not 8 + 8 + 3
+    const int n_ft = uni(tile1) - uni(tile0);                               // feature tiles tile0 .. tile1-1 of the call
+    const int i_begin = uni(tile0) * FS_FT;
+    int steps_per_tile = 0;
+    for (int p = 0; p < n_pass; p++) { const int e = p * tpp + tpp; steps_per_tile += (e < nJ ? e : nJ); }
+    const int total = n_ft * steps_per_tile;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    __syncthreads();
+    for (int p = tid; p < nJ * 16; p += nthr) {
+        loff_w[p] = (unsigned long long)W.rowid[p < M ? p : 0] * (unsigned long long)K * 8ull;
+        lmu[p] = p < M ? W.mu[p] : 0.0;
+    }
+    __syncthreads();
+    FsCur c0, c1, c2;
+    c0.i0 = i_begin; c0.pass = 0; c0.h = 0; c0.last = (tpp < nJ ? tpp : nJ) - 1;
+    c1 = c0; fs_advance(c1, n_pass, nJ, tpp);
+    c2 = c1; fs_advance(c2, n_pass, nJ, tpp);
+    d4 acc[FS_NB][FS_TPP];
+#pragma unroll
+    for (int nb = 0; nb < FS_NB; nb++)
+#pragma unroll
+        for (int t = 0; t < FS_TPP; t++) acc[nb][t] = d4{0, 0, 0, 0};
+    double pa[2][FS_PPW][4], bvr[2][FS_NB][4];
+    double qsum[FS_NB], msum[FS_NB];
+#pragma unroll
+    for (int nb = 0; nb < FS_NB; nb++) { qsum[nb] = 0; msum[nb] = 0; }
+    {   // pipeline fill: step 0's Gram operands into ring slot 0, its Sigma panels straight to LDS buffer 0,
+        // step 1's panels into ring slot 1
+        const unsigned lane_off = (unsigned)((l4 * ld + l15) * 8);
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const unsigned long long ro = loff[4 * s + l4];
+#pragma unroll
+            for (int nb = 0; nb < FS_NB; nb++) {
+                const int i = i_begin + 16 * (wave + nb * FS_NWAVES) + l15;
+                bvr[0][nb][s] = *(gptr_cd)(G + (ro + (unsigned)((i < K ? i : K - 1) * 8)));
+            }
+        }
+#pragma unroll
+        for (int pi = 0; pi < FS_PPW; pi++) {
+            const int t = wave + pi * FS_NWAVES;
+            const int J1 = c1.pass * tpp + t;
+            const bool on0 = t < tpp && t < nJ, on1 = t < tpp && J1 < nJ && c1.h <= J1;
+            const unsigned o0 = on0 ? (unsigned)(t * 16 * 8) + lane_off : 0u, st0 = on0 ? (unsigned)(4 * ld * 8) : 0u;
+            const unsigned o1 = on1 ? (unsigned)((c1.h * 16 * ld + J1 * 16) * 8) + lane_off : 0u, st1 = on1 ? (unsigned)(4 * ld * 8) : 0u;
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const double v0 = *(gptr_cd)(Sig + (o0 + s * st0));
+                pa[1][pi][s] = *(gptr_cd)(Sig + (o1 + s * st1));
+                if (on0) la[(t * 4 + s) * 64 + lane] = v0 * (0 < t ? 2.0 : 1.0);
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): nothing pending at loop entry; the compiler tracks this form
+    __syncthreads();
+    // After the last step of a feature tile every wave holds the sums of its features, spread over
+    // the four row groups of the accumulator layout: two xor-shuffles, then lanes 0..15 write them.
+#define FS_FINISH_TILE(cc)                                                                                           \
+        if ((cc).h == (cc).last && (cc).pass == n_pass - 1) {                                                        \
+            _Pragma("unroll") for (int nb = 0; nb < FS_NB; nb++) {                                                   \
+                double q = qsum[nb], m = msum[nb];                                                                   \
+                q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);                                              \
+                m += __shfl_xor(m, 16, 64); m += __shfl_xor(m, 32, 64);                                              \
+                const int i = (cc).i0 + 16 * (wave + nb * FS_NWAVES) + l15;                                          \
+                if (lane < 16 && i < K) { gSin[i] = beta - beta * q * beta; gQin[i] = beta * (gbt[i] - m); }         \
+                qsum[nb] = 0; msum[nb] = 0;                                                                          \
+            }                                                                                                        \
+        }
+#define FS_STEP(CURSLOT, gg)                                                                                         \
+        {                                                                                                            \
+            const int cb = (gg) & 1, nb_ = cb ^ 1;                                                                   \
+            fs_step_d<CURSLOT>(Sig, G, loff, lmu, la + cb * (FS_TPP * 256), la + nb_ * (FS_TPP * 256), ld, c0, c1, c2, \
+                               tpp, nJ, M, K, wave, lane, pa, bvr, acc, qsum, msum);                                 \
+            FS_FINISH_TILE(c0)                                                                                       \
+            __syncthreads();                                                                                         \
+            c0 = c1; c1 = c2; fs_advance(c2, n_pass, nJ, tpp);                                                       \
+        }
+    // whole pairs of steps without any skip path inside the loop (a skipped step would leave its
+    // predecessor's prefetch pending on the back edge: static s_waitcnt vmcnt(0)); then the odd tail
+    int g = 0;
+    for (; g + 1 < total; g += 2) {
+        FS_STEP(0, g)
+        FS_STEP(1, g + 1)
+    }
+    if (g < total) FS_STEP(0, g)
 #else
     // see fs_step.  B lives in memory (reference argument of a non-inlined function): take register
     // copies once, or every use in the loop becomes a flat load followed by s_waitcnt vmcnt(0); results
@@ -386,6 +580,7 @@ DEVNI void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W,
         FS_STEP(1, g + 1)
     }
     if (g < total) FS_STEP(0, g)
+#endif
 #undef FS_STEP
 #undef FS_FINISH_TILE
 #endif
