@@ -110,28 +110,21 @@ template <class T> DEV T *uni_ptr(T *p)
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return (T *)(((unsigned long long)hi << 32) | lo);
 }
-#ifndef FS_DIRECT_B
-#define FS_DIRECT_B 1      // Gram operand of the full-stat pass straight from memory (0: staged through LDS)
-#endif
 #ifndef FS_NB
 #define FS_NB 2            // 16-feature column blocks per wave: every Sigma panel read from LDS feeds FS_NB matrix ops
 #endif
 #define FS_TPP (16 / FS_NB) // row tiles of Sigma per pass (FS_NB x FS_TPP accumulator tiles per wave)
-#define FS_PC 16           // Gram rows staged per step (= one k-block)
 #ifndef FS_NWAVES
 #define FS_NWAVES 8        // wavefronts per fit workgroup (set by the kernel file from FIT_THREADS)
 #endif
 #define FS_FT (16 * FS_NWAVES * FS_NB)   // features per tile: every wave owns FS_NB 16-feature column blocks of it
 #define SQ_FT 128          // feature tile of the shared action mat-vecs (job board granularity)
-#define FS_NH (FS_FT / 64)       // 64-lane pieces of a staged Gram row
-#define FS_LD (FS_FT + 16)       // LDS row pitch of the Gram block in doubles (conflict-free b64 reads)
-#define FS_RPW (16 / FS_NWAVES)  // Gram rows each wave stages per step
 #define FS_PPW (FS_TPP / FS_NWAVES)   // Sigma panels each wave stages per step
-static_assert(16 % FS_NWAVES == 0 && FS_TPP % FS_NWAVES == 0 && FS_FT % 64 == 0 && 16 % FS_NB == 0, "full-stat tiling");
+static_assert(FS_TPP % FS_NWAVES == 0 && 16 % FS_NB == 0, "full-stat tiling");
 
 // The full-stat pass is ONE software pipeline over all (feature tile, pass, k-block) steps of a call:
-// a cursor names the step; what a step needs from memory is requested two steps ahead and written to
-// LDS one step ahead, across pass and tile boundaries, so memory latency is exposed once per call.
+// a cursor names the step; what a step needs from memory is requested one (Gram operands) or two
+// (Sigma panels) steps ahead, across pass and tile boundaries, so memory latency is exposed once per call.
 struct FsCur { int i0, pass, h, last; };          // feature tile origin, row-tile pass, k-block, last k-block of the pass
 DEV void fs_advance(FsCur &c, int n_pass, int nJ, int tpp)
 {
@@ -145,131 +138,36 @@ DEV void fs_advance(FsCur &c, int n_pass, int nJ, int tpp)
     }
 }
 
-// One step = k-block h (16 rows of the active set) of one pass (<= 16 row tiles of Sigma) of one
+// One step = k-block h (16 rows of the active set) of one pass (<= FS_TPP row tiles of Sigma) of one
 // feature tile.  T = Sigma * Bt on the FP64 matrix cores (v_mfma_f64_16x16x4_f64) in 16 x 16 tiles:
 //   A (16 rows of Sigma x 4 k):  lane l holds A[row = l & 15][k = l >> 4]
 //   B (4 k x 16 features):       lane l holds B[k = l >> 4][col = l & 15]
 //   D register r of lane l:      T[row = (l >> 4) + 4 r][col = l & 15]
-// Work split: every wave owns ONE 16-feature column block of the tile and ALL row tiles of the pass
-// (16 accumulator tiles), so at every step all waves do the same number of matrix ops -- the
-// triangular schedule below costs no balance.  Both operands come from LDS: the Gram k-block
-// (16 x FS_FT, shared) and the Sigma panels of the step ((tile J, k-block h) = 16 x 16, stored in
-// operand order so a wave reads one contiguous 512 B line per matrix op).  Each Sigma element is
-// fetched from memory once per workgroup and step and feeds all FS_NWAVES column blocks.
+// Work split: every wave owns FS_NB 16-feature column blocks of the tile and ALL row tiles of the pass
+// (FS_NB x FS_TPP accumulator tiles), so at every step all waves do the same number of matrix ops -- the
+// triangular schedule below costs no balance -- and every A operand read feeds FS_NB matrix ops.
+// A operand: the Sigma panels of the step ((tile J, k-block h) = 16 x 16) are identical for all waves, so
+// they are staged once per workgroup through LDS, in operand order (a wave reads one contiguous 512 B line
+// per operand); each Sigma element is fetched from memory once per workgroup and step.
+// B operand: lane l of k-group s holds G[row 16 h + 4 s + (l >> 4)][feature 16 blk + (l & 15)] -- 16
+// consecutive features of one Gram row per 16 lanes, i.e. whole 128-byte lines -- and a wave needs only its
+// own column blocks, so the Gram block is not shared through LDS at all: each wave loads its operands for
+// step g+1 straight into a register ring during step g (loff[p] = byte offset of Gram row p of the active
+// set).  Rows >= M are zeroed when they are used, so Sigma entries beyond the active block (finite: the
+// workspace is zero-initialised) contribute 0.
 // Sigma is symmetric: row tile J only visits k-blocks h <= J and counts h < J twice (the panel is
-// doubled when it is staged; doubling is exact).  Rows >= M of the Gram block are staged as zeros, so
-// Sigma entries beyond the active block (finite: the workspace is zero-initialised) contribute 0.
-// When h == J the k-block on the diagonal IS tile J's own rows: the wave folds
-// sum_j T[j][i] b_j[i] and sum_j b_j[i] mu_j for its features right there and clears the tile.
-//   * ring slot CUR (= g & 1) receives the loads of step g+2 (cursor c2); slot CUR^1 holds step g+1's
-//     data (requested during step g-1), which this step writes to the other LDS buffers.
+// doubled when it is staged; doubling is exact).
+// When h == J the k-block on the diagonal IS tile J's own rows, and the rows a lane holds as B operand
+// (4 s + l4) are exactly the rows of its accumulator registers (l4 + 4 r): the wave folds
+// sum_j T[j][i] b_j[i] and sum_j b_j[i] mu_j for its features right there from registers and clears the tile.
+//   * panel ring slot CUR (= g & 1) receives the loads of step g+2 (cursor c2); slot CUR^1 holds step g+1's
+//     panels (requested during step g-1), which this step writes to the other LDS buffer.
 // Uniform branches guard matrix ops, folds and LDS writes only -- never a load -- so the load/wait
 // bookkeeping is the same on every path (counted s_waitcnt vmcnt(N); the function must not spill and
 // nothing may be pending at loop entry, or the compiler puts a static vmcnt(0) inside the loop).
-template <int CUR>
-DEV void fs_step(gptr_cc Sig, gptr_cc G, lptr_i lused, lptr_d lmu, lptr_d bcur, lptr_d bnxt, lptr_d acur, lptr_d anxt,
-                 int ld, const FsCur &c0, const FsCur &c1, const FsCur &c2, int tpp, int nJ, int M, int K, int wave, int lane,
-                 double (&pa)[2][FS_PPW][4], double (&sv)[2][FS_RPW][FS_NH], d4 (&acc)[FS_NB][FS_TPP], double (&qsum)[FS_NB],
-                 double (&msum)[FS_NB])
-{
-    constexpr int NX = CUR ^ 1;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    // ---- requests for step g+2: Gram rows ...
-#pragma unroll
-    for (int r = 0; r < FS_RPW; r++) {
-        const int pp = c2.h * 16 + wave + r * FS_NWAVES;
-        const int rid = uni(lused[pp < M ? pp : M - 1]);
-        const gptr_cc grow = G + (size_t)rid * (size_t)K * 8;
-#pragma unroll
-        for (int e = 0; e < FS_NH; e++) {
-            const int i = c2.i0 + e * 64 + lane;
-            sv[CUR][r][e] = *(gptr_cd)(grow + (unsigned)((i < K ? i : K - 1) * 8));
-        }
-    }
-    // ... and this wave's share of the Sigma panels: element [k = 16 h + 4 s + l4][row = 16 J + l15]; ld is
-    // a multiple of 16, so whole blocks stay inside the allocation; an inactive panel reads one fixed line
-    {
-        const unsigned lane_off = (unsigned)((l4 * ld + l15) * 8);
-#pragma unroll
-        for (int pi = 0; pi < FS_PPW; pi++) {
-            const int t2 = wave + pi * FS_NWAVES, J = c2.pass * tpp + t2;
-            const bool on = t2 < tpp && J < nJ && c2.h <= J;
-            const unsigned o = on ? (unsigned)((c2.h * 16 * ld + J * 16) * 8) + lane_off : 0u;
-            const unsigned st = on ? (unsigned)(4 * ld * 8) : 0u;
-#pragma unroll
-            for (int s = 0; s < 4; s++) pa[CUR][pi][s] = *(gptr_cd)(Sig + (o + s * st));
-        }
-    }
-    // ---- matrix ops of step g
-    const int jb = c0.pass * tpp;
-    double bv[FS_NB][4];                                      // column block nb of this wave: features 16 (wave + nb FS_NWAVES) ..
-#pragma unroll
-    for (int nb = 0; nb < FS_NB; nb++)
-#pragma unroll
-        for (int s = 0; s < 4; s++) bv[nb][s] = bcur[(4 * s + l4) * FS_LD + 16 * (wave + nb * FS_NWAVES) + l15];
-#pragma unroll
-    for (int t = 0; t < FS_TPP; t++) {
-        const int J = jb + t;
-        if (t < tpp && J < nJ && c0.h <= J) {
-#pragma unroll
-            for (int s = 0; s < 4; s++) {
-                const double a = acur[(t * 4 + s) * 64 + lane];
-#pragma unroll
-                for (int nb = 0; nb < FS_NB; nb++) acc[nb][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[nb][s], acc[nb][t], 0, 0, 0);
-            }
-            if (c0.h == J) {                                  // tile J is complete: fold and clear
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const double mj = lmu[c0.h * 16 + l4 + 4 * r];
-#pragma unroll
-                    for (int nb = 0; nb < FS_NB; nb++) {
-                        const double bj = bcur[(l4 + 4 * r) * FS_LD + 16 * (wave + nb * FS_NWAVES) + l15];
-                        qsum[nb] += acc[nb][t][r] * bj;
-                        msum[nb] += bj * mj;
-                    }
-                }
-#pragma unroll
-                for (int nb = 0; nb < FS_NB; nb++) acc[nb][t] = d4{0, 0, 0, 0};
-            }
-        }
-    }
-    // ---- step g+1's operands (requested during step g-1) -> the other LDS buffers
-#pragma unroll
-    for (int r = 0; r < FS_RPW; r++) {
-        const int row = wave + r * FS_NWAVES, pp = c1.h * 16 + row;
-#pragma unroll
-        for (int e = 0; e < FS_NH; e++) asm volatile("" : "+v"(sv[NX][r][e]));   // consumed on every path
-        if (pp < M) {
-#pragma unroll
-            for (int e = 0; e < FS_NH; e++) bnxt[row * FS_LD + e * 64 + lane] = sv[NX][r][e];
-        } else {
-#pragma unroll
-            for (int e = 0; e < FS_NH; e++) bnxt[row * FS_LD + e * 64 + lane] = 0.0;
-        }
-    }
-#pragma unroll
-    for (int pi = 0; pi < FS_PPW; pi++) {
-        const int t = wave + pi * FS_NWAVES, J = c1.pass * tpp + t;
-        const double w = c1.h < J ? 2.0 : 1.0;
-#pragma unroll
-        for (int s = 0; s < 4; s++) {
-            double v = pa[NX][pi][s] * w;
-            asm volatile("" : "+v"(v));                        // consume the load on every path (see above)
-            if (t < tpp && J < nJ && c1.h <= J) anxt[(t * 4 + s) * 64 + lane] = v;
-        }
-    }
-}
-
-// The same step with the Gram operand taken straight from memory (FS_DIRECT_B): lane l of the B operand of
-// k-group s holds G[row 16 h + 4 s + (l >> 4)][feature 16 blk + (l & 15)] -- 16 consecutive features of one Gram
-// row per 16 lanes, i.e. whole 128-byte lines -- and a wave needs only its own column blocks, so nothing about
-// the Gram block has to be shared through LDS: each wave loads its operands for step g+1 into a register ring
-// during step g.  The rows a lane holds as B operand (4 s + l4) are exactly the rows of its accumulator
-// registers (l4 + 4 r), so the fold on the diagonal uses the operand registers as b_j.  Only the Sigma panels
-// (identical for all waves) still go through LDS.  loff[p] = byte offset of Gram row p of the active set.
 typedef const unsigned long long __attribute__((address_space(3))) *lptr_cull;
 template <int CUR>
-DEV void fs_step_d(gptr_cc Sig, gptr_cc G, lptr_cull loff, lptr_d lmu, lptr_d acur, lptr_d anxt,
+DEV void fs_step(gptr_cc Sig, gptr_cc G, lptr_cull loff, lptr_d lmu, lptr_d acur, lptr_d anxt,
                    int ld, const FsCur &c0, const FsCur &c1, const FsCur &c2, int tpp, int nJ, int M, int K, int wave, int lane,
                    double (&pa)[2][FS_PPW][4], double (&bvr)[2][FS_NB][4], d4 (&acc)[FS_NB][FS_TPP], double (&qsum)[FS_NB],
                    double (&msum)[FS_NB])
@@ -341,11 +239,12 @@ DEV void fs_step_d(gptr_cc Sig, gptr_cc G, lptr_cull loff, lptr_d lmu, lptr_d ac
 #pragma unroll
         for (int s = 0; s < 4; s++) {
             double v = pa[NX][pi][s] * w;
-            asm volatile("" : "+v"(v));                        // consume the load on every path (see fs_step)
+            asm volatile("" : "+v"(v));                        // consume the load on every path (see above)
             if (t < tpp && J < nJ && c1.h <= J) anxt[(t * 4 + s) * 64 + lane] = v;
         }
     }
 }
+
 #endif
 
 // S_in[i] = beta - beta^2 b_i' Sigma b_i,  Q_in[i] = beta (bt_i - b_i' mu)  for every feature,
@@ -371,8 +270,7 @@ DEVNI void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W,
         W.Qin[i] = beta * (W.bt[i] - bm);
     }
 #else
-#if FS_DIRECT_B
-    // see fs_step_d.  B lives in memory (reference argument of a non-inlined function): take register
+    // see fs_step.  B lives in memory (reference argument of a non-inlined function): take register
     // copies once, or every use in the loop becomes a flat load followed by s_waitcnt vmcnt(0); results
     // leave through global-address-space pointers for the same reason.
     const int lane = B.lane, wave = uni(B.wave), tid = B.tid, nthr = uni(B.nthr);
@@ -460,7 +358,7 @@ DEVNI void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W,
 #define FS_STEP(CURSLOT, gg)                                                                                         \
         {                                                                                                            \
             const int cb = (gg) & 1, nb_ = cb ^ 1;                                                                   \
-            fs_step_d<CURSLOT>(Sig, G, loff, lmu, la + cb * (FS_TPP * 256), la + nb_ * (FS_TPP * 256), ld, c0, c1, c2, \
+            fs_step<CURSLOT>(Sig, G, loff, lmu, la + cb * (FS_TPP * 256), la + nb_ * (FS_TPP * 256), ld, c0, c1, c2, \
                                tpp, nJ, M, K, wave, lane, pa, bvr, acc, qsum, msum);                                 \
             FS_FINISH_TILE(c0)                                                                                       \
             __syncthreads();                                                                                         \
@@ -474,113 +372,6 @@ DEVNI void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W,
         FS_STEP(1, g + 1)
     }
     if (g < total) FS_STEP(0, g)
-#else
-    // see fs_step.  B lives in memory (reference argument of a non-inlined function): take register
-    // copies once, or every use in the loop becomes a flat load followed by s_waitcnt vmcnt(0); results
-    // leave through global-address-space pointers for the same reason.
-    const int lane = B.lane, wave = uni(B.wave), tid = B.tid, nthr = uni(B.nthr);
-    const gptr_cc Sig = (gptr_cc)as_global(uni_ptr(W.Sig));
-    const gptr_cc G = (gptr_cc)as_global(uni_ptr(F.G));
-    const gptr_d gSin = as_global_rw(uni_ptr(W.Sin)), gQin = as_global_rw(uni_ptr(W.Qin));
-    const gptr_cd gbt = as_global(uni_ptr(W.bt));
-    double *pool = uni_ptr(B.pool);
-    const lptr_d lb = as_lds(pool);                                         // 2 x 16 x FS_LD   staged Gram k-blocks
-    const lptr_d la = as_lds(pool + 2 * FS_PC * FS_LD);                     // 2 x FS_TPP x 256 staged Sigma panels
-    const lptr_i lused = as_lds((int *)(pool + 2 * FS_PC * FS_LD + 2 * FS_TPP * 256));   // active-set row ids, M <= 2048
-    const lptr_d lmu = as_lds(pool + 2 * FS_PC * FS_LD + 2 * FS_TPP * 256 + 1024);        // mu, zero-padded to a k-block
-    K = uni(K); M = uni(M);
-    const int ld = uni(W.ld);
-    const int nJ = (M + 15) >> 4;
-    const int n_pass = (nJ + FS_TPP - 1) / FS_TPP;
-    const int tpp = (nJ + n_pass - 1) / n_pass;       // row tiles per pass, balanced: 19 tiles run as 10 + 9, not 16 + 3 (fewer, fuller steps)
-    const int n_ft = uni(tile1) - uni(tile0);                               // feature tiles tile0 .. tile1-1 of the call
-    const int i_begin = uni(tile0) * FS_FT;
-    int steps_per_tile = 0;
-    for (int p = 0; p < n_pass; p++) { const int e = p * tpp + tpp; steps_per_tile += (e < nJ ? e : nJ); }
-    const int total = n_ft * steps_per_tile;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    __syncthreads();
-    for (int p = tid; p < nJ * 16; p += nthr) { lused[p < M ? p : 0] = W.rowid[p < M ? p : 0]; lmu[p] = p < M ? W.mu[p] : 0.0; }
-    __syncthreads();
-    FsCur c0, c1, c2;
-    c0.i0 = i_begin; c0.pass = 0; c0.h = 0; c0.last = (tpp < nJ ? tpp : nJ) - 1;
-    c1 = c0; fs_advance(c1, n_pass, nJ, tpp);
-    c2 = c1; fs_advance(c2, n_pass, nJ, tpp);
-    d4 acc[FS_NB][FS_TPP];
-#pragma unroll
-    for (int nb = 0; nb < FS_NB; nb++)
-#pragma unroll
-        for (int t = 0; t < FS_TPP; t++) acc[nb][t] = d4{0, 0, 0, 0};
-    double pa[2][FS_PPW][4], sv[2][FS_RPW][FS_NH];
-    double qsum[FS_NB], msum[FS_NB];
-#pragma unroll
-    for (int nb = 0; nb < FS_NB; nb++) { qsum[nb] = 0; msum[nb] = 0; }
-    {   // pipeline fill: step 0's operands straight to LDS buffers 0, step 1's into ring slot 1
-        const unsigned lane_off = (unsigned)((l4 * ld + l15) * 8);
-#pragma unroll
-        for (int r = 0; r < FS_RPW; r++) {
-            const int row = wave + r * FS_NWAVES;
-            const int p0 = row, p1 = c1.h * 16 + row;
-            const gptr_cc g0 = G + (size_t)uni(lused[p0 < M ? p0 : M - 1]) * (size_t)K * 8;
-            const gptr_cc g1 = G + (size_t)uni(lused[p1 < M ? p1 : M - 1]) * (size_t)K * 8;
-#pragma unroll
-            for (int e = 0; e < FS_NH; e++) {
-                const int i_0 = i_begin + e * 64 + lane, i_1 = c1.i0 + e * 64 + lane;
-                const double v0 = *(gptr_cd)(g0 + (unsigned)((i_0 < K ? i_0 : K - 1) * 8));
-                sv[1][r][e] = *(gptr_cd)(g1 + (unsigned)((i_1 < K ? i_1 : K - 1) * 8));
-                lb[row * FS_LD + e * 64 + lane] = p0 < M ? v0 : 0.0;
-            }
-        }
-#pragma unroll
-        for (int pi = 0; pi < FS_PPW; pi++) {
-            const int t = wave + pi * FS_NWAVES;
-            const int J1 = c1.pass * tpp + t;
-            const bool on0 = t < tpp && t < nJ, on1 = t < tpp && J1 < nJ && c1.h <= J1;
-            const unsigned o0 = on0 ? (unsigned)(t * 16 * 8) + lane_off : 0u, st0 = on0 ? (unsigned)(4 * ld * 8) : 0u;
-            const unsigned o1 = on1 ? (unsigned)((c1.h * 16 * ld + J1 * 16) * 8) + lane_off : 0u, st1 = on1 ? (unsigned)(4 * ld * 8) : 0u;
-#pragma unroll
-            for (int s = 0; s < 4; s++) {
-                const double v0 = *(gptr_cd)(Sig + (o0 + s * st0));
-                pa[1][pi][s] = *(gptr_cd)(Sig + (o1 + s * st1));
-                if (on0) la[(t * 4 + s) * 64 + lane] = v0 * (0 < t ? 2.0 : 1.0);
-            }
-        }
-    }
-    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): nothing pending at loop entry; the compiler tracks this form
-    __syncthreads();
-    // After the last step of a feature tile every wave holds the sums of its 16 features, spread over
-    // the four row groups of the accumulator layout: two xor-shuffles, then lanes 0..15 write them.
-#define FS_FINISH_TILE(cc)                                                                                           \
-        if ((cc).h == (cc).last && (cc).pass == n_pass - 1) {                                                        \
-            _Pragma("unroll") for (int nb = 0; nb < FS_NB; nb++) {                                                   \
-                double q = qsum[nb], m = msum[nb];                                                                   \
-                q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);                                              \
-                m += __shfl_xor(m, 16, 64); m += __shfl_xor(m, 32, 64);                                              \
-                const int i = (cc).i0 + 16 * (wave + nb * FS_NWAVES) + l15;                                          \
-                if (lane < 16 && i < K) { gSin[i] = beta - beta * q * beta; gQin[i] = beta * (gbt[i] - m); }         \
-                qsum[nb] = 0; msum[nb] = 0;                                                                          \
-            }                                                                                                        \
-        }
-#define FS_STEP(CURSLOT, gg)                                                                                         \
-        {                                                                                                            \
-            const int cb = (gg) & 1, nb = cb ^ 1;                                                                    \
-            fs_step<CURSLOT>(Sig, G, lused, lmu, lb + cb * (FS_PC * FS_LD), lb + nb * (FS_PC * FS_LD),               \
-                             la + cb * (FS_TPP * 256), la + nb * (FS_TPP * 256), ld, c0, c1, c2, tpp, nJ, M, K,     \
-                             wave,                                                                                   \
-                             lane, pa, sv, acc, qsum, msum);                                                         \
-            FS_FINISH_TILE(c0)                                                                                       \
-            __syncthreads();                                                                                         \
-            c0 = c1; c1 = c2; fs_advance(c2, n_pass, nJ, tpp);                                                            \
-        }
-    // whole pairs of steps without any skip path inside the loop (a skipped step would leave its
-    // predecessor's prefetch pending on the back edge: static s_waitcnt vmcnt(0)); then the odd tail
-    int g = 0;
-    for (; g + 1 < total; g += 2) {
-        FS_STEP(0, g)
-        FS_STEP(1, g + 1)
-    }
-    if (g < total) FS_STEP(0, g)
-#endif
 #undef FS_STEP
 #undef FS_FINISH_TILE
 #endif
