@@ -260,9 +260,10 @@ def test_lazy_gram_rows_epistasis(golden, monkeypatch):
 
 
 def test_shared_phases_bit_identical(oracle, monkeypatch):
-    """Fewer fits than workgroups: the queue is drained at once, so every full-stat pass and action
-    mat-vec of the running fits is opened to ~200 idle workgroups (job board, CAS claims, agent-scope
-    hand-offs).  Scores, status and counters must be bit-identical to the run with sharing off."""
+    """Fewer fits than workgroups: the queue is drained at once, so every full-stat pass, action
+    mat-vec and batched-add sweep of the running fits is opened to ~200 idle workgroups (job board, CAS
+    claims, agent-scope hand-offs).  Scores, status and counters must be bit-identical to the run with
+    sharing off."""
     X, y = synthetic_gaussian(500, 4500, n_causal=25, seed=4242)
     fid = AssignToFolds(X, 3)
     alpha, lam = BuildGrid(X, y, 3)
@@ -281,6 +282,27 @@ def test_shared_phases_bit_identical(oracle, monkeypatch):
     assert np.array_equal(again[0][::-1], E1)
     Eo, _, rc = oracle.cv_grid(X, y, fid, 3, alpha[sel][:2], lam[sel][:2], n_threads=6)
     assert rc == 0 and _rel(E1[:2], Eo).max() < 1e-8
+
+
+def test_odd_feature_count_with_shared_phases(oracle, monkeypatch):
+    """p odd and not a multiple of any tile size (4357 = 17 full-stat tiles + 5 features, 34 mat-vec tiles + 5,
+    one unpaired last feature), active sets in the hundreds, every shareable phase opened from the start of
+    the launch: bit-identical to the unshared run, and both against the oracle."""
+    X, y = synthetic_gaussian(320, 4357, n_causal=30, seed=77)
+    fid = AssignToFolds(X, 3)
+    alpha, lam = BuildGrid(X, y, 3)
+    sel = np.array([130, 190, 250, 255, 310, 330])
+    out = {}
+    for share in ("0", "2"):
+        monkeypatch.setenv("PAREBEN_SHARE", share)
+        with pareben_amd.Context(X, y, fid, 3) as ctx:
+            out[share] = ctx.run(alpha[sel], lam[sel])
+    E0, st0, c0 = out["0"]
+    E2, st2, c2 = out["2"]
+    assert np.all(st2 & 8 == 0) and c2[..., 10].max() >= 96
+    assert np.array_equal(E0, E2) and np.array_equal(st0, st2) and np.array_equal(c0[..., :11], c2[..., :11])
+    Eo, _, rc = oracle.cv_grid(X, y, fid, 3, alpha[sel][:3], lam[sel][:3], n_threads=6)
+    assert rc == 0 and _rel(E2[:3], Eo).max() < 1e-8
 
 
 def test_paper_epistasis_dataset_vs_oracle(oracle):
