@@ -610,6 +610,7 @@ DEVNI int gm_delta_ml(const Blk &B, const GmWork &W, int K, int N, int M, double
 // ordered list of features with dML >= cutoff (ascending index), MainEff.c:463-473
 DEVNI int gm_collect(const Blk &B, const GmWork &W, int K, double cutoff)
 {
+#ifdef PAREBEN_HOST_EMUL
     int base = 0;
     for (int i0 = 0; i0 < K; i0 += B.nthr) {
         const int i = i0 + B.tid;
@@ -621,6 +622,18 @@ DEVNI int gm_collect(const Blk &B, const GmWork &W, int K, double cutoff)
     }
     blk_sync(B);
     return base;
+#else
+    // every thread takes a contiguous slice of the features: one count, ONE block scan, one ordered write
+    const int per = (K + B.nthr - 1) / B.nthr, i0 = B.tid * per, i1 = i0 + per < K ? i0 + per : K;
+    const gptr_cd dml = as_global(W.dml);
+    int n = 0;
+    for (int i = i0; i < i1; i++) n += dml[i] >= cutoff ? 1 : 0;
+    int tot;
+    int off = blk_scan_excl(B, n, &tot);
+    if (n) for (int i = i0; i < i1; i++) if (dml[i] >= cutoff) W.todo[off++] = i;
+    blk_sync(B);
+    return tot;
+#endif
 }
 
 // S_in / Q_in update of feature i from a = sum_j G[used[j], i] * vec[j].
@@ -1672,6 +1685,22 @@ DEV double gm_model_at(const Blk &B, const FoldDev &F, const GmWork &, int M, co
     for (int j = 0; j < M; j++) v += lc[j] * (X[(size_t)lu[j] * N + h] * lr[j]);
     return v;
 }
+// two samples at once (twice the design-column loads in flight; each sum is the same chain as above)
+DEV void gm_model_at2(const Blk &B, const FoldDev &F, int M, int N, int h0, int h1, double &v0, double &v1)
+{
+    const lptr_d lc = as_lds(B.pool), lr = as_lds(B.pool + M);
+    const lptr_i lu = as_lds((int *)(B.pool + 2 * M));
+    const gptr_cd X = as_global(F.X);
+    double a0 = 0, a1 = 0;
+#pragma unroll 4
+    for (int j = 0; j < M; j++) {
+        const size_t col = (size_t)lu[j] * N;
+        const double c = lc[j], r = lr[j];
+        a0 += c * (X[col + h0] * r);
+        a1 += c * (X[col + h1] * r);
+    }
+    v0 = a0; v1 = a1;
+}
 #endif
 
 // One call of the inner routine (MainEff.c:248-809) for outer iteration `iter`.  On return
@@ -1837,11 +1866,22 @@ DEV int gm_inner(const Blk &B, const FoldDev &F, const GmWork &W, int K, double 
             PH_BEGIN();
             double ee_part = 0;
             gm_stage_model(B, F, W, M, W.mu);
+#ifdef PAREBEN_HOST_EMUL
             PAR(h, N) {
                 const double pm = gm_model_at(B, F, W, M, W.mu, N, h);
                 const double e = (F.y[h] - S.b) - pm;
                 ee_part += e * e;
             }
+#else
+            for (int h = B.tid; h < N; h += 2 * B.nthr) {     // a thread's samples in the same order, two per trip
+                const int h2 = h + B.nthr;
+                double pm0, pm1;
+                gm_model_at2(B, F, M, N, h, h2 < N ? h2 : h, pm0, pm1);
+                const double e0 = (F.y[h] - S.b) - pm0;
+                ee_part += e0 * e0;
+                if (h2 < N) { const double e1 = (F.y[h2] - S.b) - pm1; ee_part += e1 * e1; }
+            }
+#endif
             const double ee = blk_sum(B, ee_part);
             double g_part = 0;
             PAR(i, M) g_part += W.gam[i];
@@ -1875,12 +1915,24 @@ DEV int gm_inner(const Blk &B, const FoldDev &F, const GmWork &W, int K, double 
         const double beta = S.beta, b2 = beta * beta;
         double a_part = 0, b_part = 0;
         gm_stage_model(B, F, W, M, W.v2);
+#ifdef PAREBEN_HOST_EMUL
         PAR(h, N) {
             const double v = gm_model_at(B, F, W, M, W.v2, N, h);
             const double c = beta - b2 * v;
             a_part += c;
             b_part += c * F.y[h];
         }
+#else
+        for (int h = B.tid; h < N; h += 2 * B.nthr) {
+            const int h2 = h + B.nthr;
+            double v0, v1;
+            gm_model_at2(B, F, M, N, h, h2 < N ? h2 : h, v0, v1);
+            const double c0 = beta - b2 * v0;
+            a_part += c0;
+            b_part += c0 * F.y[h];
+            if (h2 < N) { const double c1 = beta - b2 * v1; a_part += c1; b_part += c1 * F.y[h2]; }
+        }
+#endif
         *cs = blk_sum(B, a_part);
         *csy = blk_sum(B, b_part);
     }
