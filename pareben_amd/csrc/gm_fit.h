@@ -539,10 +539,24 @@ DEVNI int gm_delta_ml(const Blk &B, const GmWork &W, int K, int N, int M, double
     if (epis ? (M > 100 || residual <= varY * 0.1)                    // Full2.c:1257
              : (M > 100 || M >= N || residual <= varY * 0.1)) { prio_add = 0; prio_del = 1; }
     int my_add = 0, my_del = 0;
+    double v1 = 0; int idx1 = 0x7fffffff;                     // arg-max of this pass (valid when no rescan follows)
+#ifdef PAREBEN_HOST_EMUL
     PAR(i, K) {
         const int l = W.upos[i];
         if (l == UP_LOST) { W.act[i] = ACT_NONE; continue; }   // in neither list: stale dML stays
         const double so = W.Sout[i], qo = W.Qout[i];
+#else
+    // the three loads of the next feature are issued before the (long) arithmetic of this one
+    const gptr_ci g_upos = as_global(W.upos);
+    const gptr_cd g_so = as_global(W.Sout), g_qo = as_global(W.Qout);
+    int l_n = 0; double so_n = 0, qo_n = 0;
+    if (B.tid < K) { l_n = g_upos[B.tid]; so_n = g_so[B.tid]; qo_n = g_qo[B.tid]; }
+    PAR(i, K) {
+        const int l = l_n;
+        const double so = so_n, qo = qo_n;
+        { const int in = i + B.nthr; if (in < K) { l_n = g_upos[in]; so_n = g_so[in]; qo_n = g_qo[in]; } }
+        if (l == UP_LOST) { W.act[i] = ACT_NONE; continue; }   // in neither list: stale dML stays
+#endif
         double d_ml = 0;
         int act = ACT_NONE;
         const double a = so - qo * qo + 2 * l1 + l2;
@@ -575,6 +589,7 @@ DEVNI int gm_delta_ml(const Blk &B, const GmWork &W, int K, int N, int M, double
         }
         W.act[i] = (signed char)act;
         W.dml[i] = d_ml;
+        if (d_ml > v1) { v1 = d_ml; idx1 = i; }
     }
     const int any_add = blk_or(B, my_add);
     const int any_del = blk_or(B, my_del);
@@ -595,11 +610,12 @@ DEVNI int gm_delta_ml(const Blk &B, const GmWork &W, int K, int N, int M, double
     }
     blk_sync(B);
     double v = 0; int idx = 0x7fffffff;
-    PAR(i, K) {
-        if (!rescanned && W.upos[i] == UP_LOST) continue;    // first scan walks the two lists only
-        const double d = W.dml[i];
-        if (d > v) { v = d; idx = i; }
-    }
+    if (rescanned) {
+        PAR(i, K) {
+            const double d = W.dml[i];
+            if (d > v) { v = d; idx = i; }
+        }
+    } else { v = v1; idx = idx1; }                            // first scan walks the two lists only: what the pass above saw
     double bv; int bi;
     blk_argmax(B, v, idx, &bv, &bi);
     if (!(bv > 0)) { bv = 0; bi = 0; }
