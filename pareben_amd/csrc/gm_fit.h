@@ -383,7 +383,7 @@ DEVNI void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W,
 // work queue is drained the workgroups that are out of fits would sit idle while those finish.  The
 // full-stat pass (half of a heavy fit's time) and the K x M mat-vec of every action are independent
 // per feature, so in that phase of the launch an owner OPENS each of them (FsJob): idle workgroups
-// claim chunks of 128-feature tiles by compare-and-swap on (epoch, next tile), run the same code on
+// claim chunks of feature tiles (FS_FT or SQ_FT features each) by compare-and-swap on (epoch, next tile), run the same code on
 // the owner's state in HBM (Sigma / mu / row ids, or the action's vector) and write S_in / Q_in for
 // their features; the owner works on its own job too and waits for the chunk count.  Results do not
 // depend on who computed a feature (same code, same order).

@@ -74,7 +74,7 @@ struct GmWork {
 struct FsJob {
     unsigned long long word;
     int done;              // chunks finished (by anyone)
-    int fold, M, n_tiles;  // n_tiles: 128-feature tiles of the K features
+    int fold, M, n_tiles;  // n_tiles: feature tiles of the job (256 features for a full-stat pass, 128 for a sweep)
     int kind, mode, rid;   // JOB_FULLSTAT | JOB_SQ; for JOB_SQ the update mode and the new feature's Gram row id
     int pad;
     double beta, c1, c2;   // one 64-byte line per job
