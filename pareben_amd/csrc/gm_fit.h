@@ -64,6 +64,7 @@ struct GmScalars {
     const FsShare *share = nullptr;   // shared full-stat passes (device only; null = off)
     int fold = 0;
     int bp_ok = 0;     // binomial: model columns for which the weighted rows BP are current (0 = stale)
+    int gc_ok = 0;     // Gaussian, device: the Gram block cache W.Gc matches the active set's slots (0 = rebuild at the next Hessian)
 };
 #define CNT(stmt) do { if (B.tid == 0) { FitCounters &c = *S.c; stmt; } } while (0)
 
@@ -1079,6 +1080,13 @@ DEVNI void gm_add(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScal
         W.rowid[M] = rid;
         W.upos[nu] = M;
     }
+#ifndef PAREBEN_HOST_EMUL
+    if (S.gc_ok) {                                            // the new slot's column of the Gram block cache
+        const gptr_cd G = as_global(F.G);
+        PAR(j, M) W.Gc[(size_t)j * ld + M] = G[(size_t)W.rowid[j] * K + nu];
+        if (B.tid == 0) W.Gc[(size_t)M * ld + M] = G[(size_t)rid * K + nu];
+    }
+#endif
     gm_sq_update(B, F, W, K, M, W.v2, 1, beta, sii, mui, rid, S);
     GM_TRACE("    add nu=%d newA=%.15g sii=%.15g mui=%.15g tp0=%.15g tmp0=%.15g Sin=%.15g Qin=%.15g mu0=%.15g\n", nu, newA, sii, mui, W.v2[0], W.v1[0], W.Sin[nu], W.Qin[nu], W.mu[0]);
     S.M = M + 1;
@@ -1293,7 +1301,7 @@ DEVNI void gm_add_batch(const Blk &B, const FoldDev &F, const GmWork &W, int K, 
     blk_sync(B);
     for (int e = B.tid; e < T * Mt; e += B.nthr) {
         const int u = e / Mt, j = e - u * Mt;
-        gb[e] = u >= 1 ? G[(size_t)lrow[j] * K + nus[u]] : 0.0;
+        gb[e] = G[(size_t)lrow[j] * K + nus[u]];
     }
     blk_sync(B);
     for (int t = 0; t < T; t++) {
@@ -1339,6 +1347,7 @@ DEVNI void gm_add_batch(const Blk &B, const FoldDev &F, const GmWork &W, int K, 
             W.upos[nu] = M;
             sii_v[t] = sii; mui_v[t] = mui;
         }
+        if (S.gc_ok) PAR(j, M + 1) W.Gc[(size_t)j * ld + M] = gb[(size_t)t * Mt + j];   // the new slot's column of the Gram block cache
         blk_sync(B);
     }
     PH_BEGIN();
@@ -1387,6 +1396,7 @@ DEVNI void gm_delete(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmS
         if (F.lazy && gone_row >= W.priv_base && gone_row < W.priv_base + W.priv_rows) W.pfree[++W.pfree[0]] = gone_row;
     }
     S.M = last;
+    S.gc_ok = 0;                                              // slots were reshuffled: the next Hessian regathers its Gram block
     blk_sync(B);
 }
 
@@ -1614,30 +1624,41 @@ DEVNI int gm_final_update(const Blk &B, const FoldDev &F, const GmWork &W, int K
         PAR(l, M) { lu[l] = W.used[l]; lr[l] = W.rowid[l]; la[l] = W.A[l]; }
         blk_sync(B);
         const gptr_cd G = as_global(F.G);
-        const gptr_d H = as_global_rw(W.H), Sg = as_global_rw(W.Sig);
+        const gptr_d H = as_global_rw(W.H), Sg = as_global_rw(W.Sig), Gc = as_global_rw(W.Gc);
+        const bool cached = S.gc_ok != 0;
+        // the blocked inverse reads and writes only the triangle [j][i >= j] (and mirrors Sigma itself at the end);
+        // the scattered mirror stores are needed only in front of the scalar inverse (M <= 16, or no LDS room)
+        const bool mirror = !(M > 16 && ((M + 15) >> 4) * 16 * INV_TP + 16 * 17 <= B.pool_n);
         for (int j = B.wave; j < M; j += B.nwave) {
             const size_t rj = (size_t)lr[j] * K;
-            // Phi_i.Phi_j from the Gram matrix: element (j, i >= j) is read from Gram row j (one row per
-            // wave trip, not a column walk across M rows) and mirrored, so H is exactly symmetric.  Four
-            // gathers are issued before the first store so that they overlap.
+            // Phi_i.Phi_j from the Gram matrix: element (j, i >= j) is G[row_j][used_i] -- gathered from Gram row j
+            // (one row per wave trip, not a column walk across M rows) the first time and after a delete has
+            // reshuffled the slots, otherwise taken from the fit's own copy of that block, which every add extends
+            // by one column (gm_add, gm_add_batch): a coalesced read instead of M^2/2 gathers.  One triangle stands for
+            // both, so H is exactly symmetric.  Four loads are issued before the first store so that they overlap.
             for (int i0 = j + B.lane; i0 < M; i0 += 4 * BLK_LANES) {
                 double h[4];
 #pragma unroll
-                for (int c = 0; c < 4; c++) { const int i = i0 + c * BLK_LANES; h[c] = i < M ? G[rj + lu[i]] : 0.0; }
+                for (int c = 0; c < 4; c++) {
+                    const int i = i0 + c * BLK_LANES;
+                    h[c] = i < M ? (cached ? Gc[(size_t)j * ld + i] : G[rj + lu[i]]) : 0.0;
+                }
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
                     const int i = i0 + c * BLK_LANES;
                     if (i < M) {
+                        if (!cached) Gc[(size_t)j * ld + i] = h[c];
                         double v = h[c] * beta;
                         if (i == j) v += la[i];
                         H[(size_t)j * ld + i] = v;
                         Sg[(size_t)j * ld + i] = v;
-                        if (i != j) { H[(size_t)i * ld + j] = v; Sg[(size_t)i * ld + j] = v; }
+                        if (mirror && i != j) { H[(size_t)i * ld + j] = v; Sg[(size_t)i * ld + j] = v; }
                     }
                 }
             }
         }
         blk_sync(B);
+        S.gc_ok = 1;
         PH_END(PH_HBUILD);
     }
 #endif
@@ -1962,6 +1983,7 @@ DEV void gm_fit(const Blk &B, const FoldDev &F, const GmWork &W, int K, double l
 {
     S.b = F.ymean;
     S.status = 0;
+    S.gc_ok = 0;
     S.M = 1;
     CNT(c = FitCounters{});
     const double varT = F.varY;

@@ -203,7 +203,7 @@ static WsLayout ws_layout(int K, int cap)
     L.cap = cap; L.ld = (cap + 15) / 16 * 16;      // whole 16-row blocks: the matrix-core passes index rows without clamps
     size_t o = 0;
     L.offK = o;   o += align_up((size_t)K * (7 * sizeof(double) + 2 * sizeof(int) + 1), 256);
-    L.offSig = o; o += align_up((size_t)2 * L.ld * L.ld * sizeof(double), 256);
+    L.offSig = o; o += align_up((size_t)3 * L.ld * L.ld * sizeof(double), 256);      // Sigma, H, Gram block cache
     L.offM = o;   o += align_up((size_t)(cap + 2) * ((7 + ADD_TB) * sizeof(double) + 3 * sizeof(int)) + 4 * ADD_TB * sizeof(double), 256);
     L.bytes = align_up(o, 4096);
     return L;
@@ -220,7 +220,7 @@ __device__ inline GmWork ws_carve(char *base, int K, int cap, size_t offK, size_
     W.act = (signed char *)ip;
     d = (double *)(base + offSig);
     const int ldp = (cap + 15) / 16 * 16;
-    W.Sig = d; d += (size_t)ldp * ldp; W.H = d;
+    W.Sig = d; d += (size_t)ldp * ldp; W.H = d; d += (size_t)ldp * ldp; W.Gc = d;
     d = (double *)(base + offM);
     const int c1 = cap + 1;
     W.A = d; d += c1; W.mu = d; d += c1; W.gam = d; d += c1;
@@ -556,11 +556,11 @@ __global__ __launch_bounds__(FIT_THREADS) void gm_fit_kernel(FitParams P)
         P.Beta[3 * (size_t)K + f] = W.Sig[(size_t)i * ld + i] / (sc * sc);
         if (P.v.epis) P.Beta[4 * (size_t)K + f] = f + 1;
     }
-    // Wald score mu' H mu with the H of the last final update (:199-215)
+    // Wald score mu' H mu with the H of the last final update (:199-215); H is held as its triangle [j][i >= j]
     double part = 0;
     PAR(i, M) {
         double a = 0;
-        for (int j = 0; j < M; j++) a += W.mu[j] * W.H[(size_t)i * ld + j];
+        for (int j = 0; j < M; j++) a += W.mu[j] * W.H[i < j ? (size_t)i * ld + j : (size_t)j * ld + i];
         part += a * W.mu[i];
     }
     const double wald = blk_sum(B, part);
