@@ -1480,24 +1480,26 @@ DEVNI int gm_spd_inverse_blocked(const Blk &B, const GmWork &W, int M, long long
         }
         PHX_END(t_piv, PH_INV_PIVOT);
         PHX_BEGIN(t_tn);
-        // Tn[i][r] = sum_s A(i, k0+s) * nD[s][r] for rows outside the block (zero inside / padding)
-        for (int i = B.tid; i < Mp; i += B.nthr) {
-            double lp[16];
+        // Tn[i][r] = sum_s A(i, k0+s) * nD[s][r] for rows outside the block (zero inside / padding): one 16 x 16 x 16
+        // product per row tile on the matrix cores (four chained ops = the same k-ascending fma chain a scalar loop
+        // runs, tools/ubench/mfma_f64_order.hip); rows <-> i, columns <-> r
+        for (int ti = B.wave; ti < nT; ti += B.nwave) {
+            const int i = ti * 16 + l15;
             const bool live = i < M && (i < k0 || i >= k0 + 16);
+            d4 acc = d4{0, 0, 0, 0};
+            double av[4], bw[4];
 #pragma unroll
-            for (int s2 = 0; s2 < 16; s2++) {
-                const int kc = k0 + s2;
+            for (int kk = 0; kk < 4; kk++) {
+                const int kc = k0 + kk * 4 + l4;
                 double v = 0;
                 if (live && kc < M) v = (i > kc) ? Sig[(size_t)kc * ld + i] : Sig[(size_t)i * ld + kc];
-                lp[s2] = v;
+                av[kk] = v;
+                bw[kk] = nD[(kk * 4 + l4) * 17 + l15];
             }
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                double t = 0;
+            for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bw[kk], acc, 0, 0, 0);
 #pragma unroll
-                for (int s2 = 0; s2 < 16; s2++) t += lp[s2] * nD[s2 * 17 + r];
-                Tn[(size_t)i * INV_TP + r] = t;
-            }
+            for (int r = 0; r < 4; r++) Tn[(size_t)(ti * 16 + l4 + 4 * r) * INV_TP + l15] = acc[r];
         }
         __syncthreads();
         PHX_END(t_tn, PH_INV_TN);
