@@ -1449,6 +1449,7 @@ DEVNI int gm_spd_inverse_blocked(const Blk &B, const GmWork &W, int M, long long
     const int nT = (M + 15) >> 4, Mp = nT * 16;
     const lptr_d Tn = as_lds(B.pool);
     const lptr_d nD = Tn + (size_t)Mp * INV_TP;              // 16 x 17
+    const lptr_d nD2 = nD + 16 * 17;                         // second copy for the pivot sweeps
     const int l15 = B.lane & 15, l4 = B.lane >> 4;
     for (int tk = 0; tk < nT; tk++) {
         const int k0 = tk * 16;
@@ -1462,22 +1463,22 @@ DEVNI int gm_spd_inverse_blocked(const Blk &B, const GmWork &W, int M, long long
             nD[r * 17 + c] = v;
         }
         __syncthreads();
-        for (int s = 0; s < 16; s++) {                        // scalar sweeps inside the block
-            const double d = nD[s * 17 + s];
+        for (int s = 0; s < 16; s++) {                        // scalar sweeps inside the block, ping-pong between two
+            const lptr_d src = (s & 1) ? nD2 : nD, dst = (s & 1) ? nD : nD2;   // copies: one barrier per sweep
+            const double d = src[s * 17 + s];
             if (!(d > 0)) return 1;
-            double nv = 0;
             if (B.tid < 256) {
                 const int r = B.tid & 15, c = B.tid >> 4;
-                const double prs = nD[r * 17 + s], psc = nD[s * 17 + c], v = nD[r * 17 + c];
+                const double prs = src[r * 17 + s], psc = src[s * 17 + c], v = src[r * 17 + c];
+                double nv;
                 if (r == s && c == s) nv = -1.0 / d;
                 else if (r == s) nv = psc / d;
                 else if (c == s) nv = prs / d;
                 else nv = v - prs * psc / d;
+                dst[r * 17 + c] = nv;
             }
             __syncthreads();
-            if (B.tid < 256) nD[(B.tid & 15) * 17 + (B.tid >> 4)] = nv;
-            __syncthreads();
-        }
+        }                                                     // 16 sweeps: the result is back in nD
         PHX_END(t_piv, PH_INV_PIVOT);
         PHX_BEGIN(t_tn);
         // Tn[i][r] = sum_s A(i, k0+s) * nD[s][r] for rows outside the block (zero inside / padding): one 16 x 16 x 16
@@ -1595,7 +1596,7 @@ DEV int gm_spd_inverse(const Blk &B, const GmWork &W, int M, long long *phx = nu
     (void)phx;
 #ifndef PAREBEN_HOST_EMUL
     const int Mp = ((M + 15) >> 4) * 16;
-    if (M > 16 && Mp * INV_TP + 16 * 17 <= B.pool_n) return gm_spd_inverse_blocked(B, W, M, phx);
+    if (M > 16 && Mp * INV_TP + 2 * 16 * 17 <= B.pool_n) return gm_spd_inverse_blocked(B, W, M, phx);
 #endif
     return gm_spd_inverse_scalar(B, W, M);
 }
@@ -1630,7 +1631,7 @@ DEVNI int gm_final_update(const Blk &B, const FoldDev &F, const GmWork &W, int K
         const bool cached = S.gc_ok != 0;
         // the blocked inverse reads and writes only the triangle [j][i >= j] (and mirrors Sigma itself at the end);
         // the scattered mirror stores are needed only in front of the scalar inverse (M <= 16, or no LDS room)
-        const bool mirror = !(M > 16 && ((M + 15) >> 4) * 16 * INV_TP + 16 * 17 <= B.pool_n);
+        const bool mirror = !(M > 16 && ((M + 15) >> 4) * 16 * INV_TP + 2 * 16 * 17 <= B.pool_n);
         for (int j = B.wave; j < M; j += B.nwave) {
             const size_t rj = (size_t)lr[j] * K;
             // Phi_i.Phi_j from the Gram matrix: element (j, i >= j) is G[row_j][used_i] -- gathered from Gram row j
