@@ -120,6 +120,9 @@ template <class T> DEV T *uni_ptr(T *p)
 #endif
 #define FS_FT (16 * FS_NWAVES * FS_NB)   // features per tile: every wave owns FS_NB 16-feature column blocks of it
 #define SQ_FT 128          // feature tile of the shared action mat-vecs (job board granularity)
+#ifndef FS_APRE
+#define FS_APRE 1           // tiles by which the LDS reads of the A operands run ahead of the matrix ops
+#endif
 #define FS_PPW (FS_TPP / FS_NWAVES)   // Sigma panels each wave stages per step
 static_assert(FS_TPP % FS_NWAVES == 0 && 16 % FS_NB == 0, "full-stat tiling");
 
@@ -207,13 +210,28 @@ DEV void fs_step(gptr_cc Sig, gptr_cc G, lptr_cull loff, lptr_d lmu, lptr_d acur
 #pragma unroll
         for (int nb = 0; nb < FS_NB; nb++) bv[nb][s] = live ? bvr[CUR][nb][s] : 0.0;
     }
+    // The A operands of tile t+1 are read from LDS before the matrix ops of tile t are issued (FS_APRE tiles ahead
+    // through a small register ring), so no LDS latency sits between two tiles' matrix ops; the reads are
+    // unconditional (every slot of the buffer is addressable), only the matrix ops are guarded.
+    double an[FS_APRE][4];
+#pragma unroll
+    for (int p = 0; p < FS_APRE; p++)
+#pragma unroll
+        for (int s = 0; s < 4; s++) an[p][s] = acur[(p * 4 + s) * 64 + lane];
 #pragma unroll
     for (int t = 0; t < FS_TPP; t++) {
         const int J = jb + t;
+        double ac[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) ac[s] = an[t % FS_APRE][s];
+        if (t + FS_APRE < FS_TPP) {
+#pragma unroll
+            for (int s = 0; s < 4; s++) an[t % FS_APRE][s] = acur[((t + FS_APRE) * 4 + s) * 64 + lane];
+        }
         if (t < tpp && J < nJ && c0.h <= J) {
 #pragma unroll
             for (int s = 0; s < 4; s++) {
-                const double a = acur[(t * 4 + s) * 64 + lane];
+                const double a = ac[s];
 #pragma unroll
                 for (int nb = 0; nb < FS_NB; nb++) acc[nb][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[nb][s], acc[nb][t], 0, 0, 0);
             }
