@@ -130,15 +130,21 @@ static_assert(FS_TPP % FS_NWAVES == 0 && 16 % FS_NB == 0, "full-stat tiling");
 // a cursor names the step; what a step needs from memory is requested one (Gram operands) or two
 // (Sigma panels) steps ahead, across pass and tile boundaries, so memory latency is exposed once per call.
 struct FsCur { int i0, pass, h, last; };          // feature tile origin, row-tile pass, k-block, last k-block of the pass
-DEV void fs_advance(FsCur &c, int n_pass, int nJ, int tpp)
+// Row tiles are cut into passes of at most FS_TPP; a pass visits the k-blocks 0 .. (its last tile), so the number of
+// steps of a feature tile is the sum of the passes' end indices: smallest when the LATER passes are full and the
+// first one takes the remainder (19 tiles: 3 + 8 + 8 -> 3 + 11 + 19 = 33 steps; 7 + 6 + 6 would be 39, 8 + 8 + 3: 43).
+// `first` = tiles of pass 0.
+DEV int fs_pass_begin(int pass, int first) { return pass == 0 ? 0 : first + (pass - 1) * FS_TPP; }
+DEV int fs_pass_end(int pass, int first) { return first + pass * FS_TPP; }          // exclusive; the last pass ends at nJ
+DEV void fs_advance(FsCur &c, int n_pass, int nJ, int first)
 {
     c.h++;
     if (c.h > c.last) {
         c.h = 0;
         c.pass++;
         if (c.pass == n_pass) { c.pass = 0; c.i0 += FS_FT; }
-        const int e = c.pass * tpp + tpp;
-        c.last = (e < nJ ? e : nJ) - 1;
+        (void)nJ;
+        c.last = fs_pass_end(c.pass, first) - 1;
     }
 }
 
@@ -172,7 +178,7 @@ DEV void fs_advance(FsCur &c, int n_pass, int nJ, int tpp)
 typedef const unsigned long long __attribute__((address_space(3))) *lptr_cull;
 template <int CUR>
 DEV void fs_step(gptr_cc Sig, gptr_cc G, lptr_cull loff, lptr_d lmu, lptr_d acur, lptr_d anxt,
-                   int ld, const FsCur &c0, const FsCur &c1, const FsCur &c2, int tpp, int nJ, int M, int K, int wave, int lane,
+                   int ld, const FsCur &c0, const FsCur &c1, const FsCur &c2, int first, int nJ, int M, int K, int wave, int lane,
                    double (&pa)[2][FS_PPW][4], double (&bvr)[2][FS_NB][4], d4 (&acc)[FS_NB][FS_TPP], double (&qsum)[FS_NB],
                    double (&msum)[FS_NB])
 {
@@ -183,8 +189,8 @@ DEV void fs_step(gptr_cc Sig, gptr_cc G, lptr_cull loff, lptr_d lmu, lptr_d acur
         const unsigned lane_off = (unsigned)((l4 * ld + l15) * 8);
 #pragma unroll
         for (int pi = 0; pi < FS_PPW; pi++) {
-            const int t2 = wave + pi * FS_NWAVES, J = c2.pass * tpp + t2;
-            const bool on = t2 < tpp && J < nJ && c2.h <= J;
+            const int t2 = wave + pi * FS_NWAVES, J = fs_pass_begin(c2.pass, first) + t2;
+            const bool on = J < fs_pass_end(c2.pass, first) && c2.h <= J;
             const unsigned o = on ? (unsigned)((c2.h * 16 * ld + J * 16) * 8) + lane_off : 0u;
             const unsigned st = on ? (unsigned)(4 * ld * 8) : 0u;
 #pragma unroll
@@ -202,7 +208,7 @@ DEV void fs_step(gptr_cc Sig, gptr_cc G, lptr_cull loff, lptr_d lmu, lptr_d acur
         }
     }
     // ---- matrix ops of step g; rows beyond the active set contribute zero
-    const int jb = c0.pass * tpp;
+    const int jb = fs_pass_begin(c0.pass, first), je = fs_pass_end(c0.pass, first);
     double bv[FS_NB][4];
 #pragma unroll
     for (int s = 0; s < 4; s++) {
@@ -228,7 +234,7 @@ DEV void fs_step(gptr_cc Sig, gptr_cc G, lptr_cull loff, lptr_d lmu, lptr_d acur
 #pragma unroll
             for (int s = 0; s < 4; s++) an[t % FS_APRE][s] = acur[((t + FS_APRE) * 4 + s) * 64 + lane];
         }
-        if (t < tpp && J < nJ && c0.h <= J) {
+        if (J < je && c0.h <= J) {
 #pragma unroll
             for (int s = 0; s < 4; s++) {
                 const double a = ac[s];
@@ -253,13 +259,13 @@ DEV void fs_step(gptr_cc Sig, gptr_cc G, lptr_cull loff, lptr_d lmu, lptr_d acur
     // ---- step g+1's Sigma panels (requested during step g-1) -> the other LDS buffer
 #pragma unroll
     for (int pi = 0; pi < FS_PPW; pi++) {
-        const int t = wave + pi * FS_NWAVES, J = c1.pass * tpp + t;
+        const int t = wave + pi * FS_NWAVES, J = fs_pass_begin(c1.pass, first) + t;
         const double w = c1.h < J ? 2.0 : 1.0;
 #pragma unroll
         for (int s = 0; s < 4; s++) {
             double v = pa[NX][pi][s] * w;
             asm volatile("" : "+v"(v));                        // consume the load on every path (see above)
-            if (t < tpp && J < nJ && c1.h <= J) anxt[(t * 4 + s) * 64 + lane] = v;
+            if (J < fs_pass_end(c1.pass, first) && c1.h <= J) anxt[(t * 4 + s) * 64 + lane] = v;
         }
     }
 }
@@ -306,11 +312,11 @@ DEVNI void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W,
     const int ld = uni(W.ld);
     const int nJ = (M + 15) >> 4;
     const int n_pass = (nJ + FS_TPP - 1) / FS_TPP;
-    const int tpp = (nJ + n_pass - 1) / n_pass;       // row tiles per pass, balanced: 19 tiles run as 7 + 6 + 6, not 8 + 8 + 3
+    const int first = nJ - (n_pass - 1) * FS_TPP;     // row tiles of pass 0; the later passes are full (see fs_pass_end)
     const int n_ft = uni(tile1) - uni(tile0);                               // feature tiles tile0 .. tile1-1 of the call
     const int i_begin = uni(tile0) * FS_FT;
     int steps_per_tile = 0;
-    for (int p = 0; p < n_pass; p++) { const int e = p * tpp + tpp; steps_per_tile += (e < nJ ? e : nJ); }
+    for (int p = 0; p < n_pass; p++) steps_per_tile += fs_pass_end(p, first);
     const int total = n_ft * steps_per_tile;
     const int l15 = lane & 15, l4 = lane >> 4;
     __syncthreads();
@@ -320,9 +326,9 @@ DEVNI void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W,
     }
     __syncthreads();
     FsCur c0, c1, c2;
-    c0.i0 = i_begin; c0.pass = 0; c0.h = 0; c0.last = (tpp < nJ ? tpp : nJ) - 1;
-    c1 = c0; fs_advance(c1, n_pass, nJ, tpp);
-    c2 = c1; fs_advance(c2, n_pass, nJ, tpp);
+    c0.i0 = i_begin; c0.pass = 0; c0.h = 0; c0.last = first - 1;
+    c1 = c0; fs_advance(c1, n_pass, nJ, first);
+    c2 = c1; fs_advance(c2, n_pass, nJ, first);
     d4 acc[FS_NB][FS_TPP];
 #pragma unroll
     for (int nb = 0; nb < FS_NB; nb++)
@@ -347,8 +353,8 @@ DEVNI void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W,
 #pragma unroll
         for (int pi = 0; pi < FS_PPW; pi++) {
             const int t = wave + pi * FS_NWAVES;
-            const int J1 = c1.pass * tpp + t;
-            const bool on0 = t < tpp && t < nJ, on1 = t < tpp && J1 < nJ && c1.h <= J1;
+            const int J1 = fs_pass_begin(c1.pass, first) + t;
+            const bool on0 = t < first, on1 = J1 < fs_pass_end(c1.pass, first) && c1.h <= J1;
             const unsigned o0 = on0 ? (unsigned)(t * 16 * 8) + lane_off : 0u, st0 = on0 ? (unsigned)(4 * ld * 8) : 0u;
             const unsigned o1 = on1 ? (unsigned)((c1.h * 16 * ld + J1 * 16) * 8) + lane_off : 0u, st1 = on1 ? (unsigned)(4 * ld * 8) : 0u;
 #pragma unroll
@@ -378,10 +384,10 @@ DEVNI void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W,
         {                                                                                                            \
             const int cb = (gg) & 1, nb_ = cb ^ 1;                                                                   \
             fs_step<CURSLOT>(Sig, G, loff, lmu, la + cb * (FS_TPP * 256), la + nb_ * (FS_TPP * 256), ld, c0, c1, c2, \
-                               tpp, nJ, M, K, wave, lane, pa, bvr, acc, qsum, msum);                                 \
+                               first, nJ, M, K, wave, lane, pa, bvr, acc, qsum, msum);                                 \
             FS_FINISH_TILE(c0)                                                                                       \
             __syncthreads();                                                                                         \
-            c0 = c1; c1 = c2; fs_advance(c2, n_pass, nJ, tpp);                                                       \
+            c0 = c1; c1 = c2; fs_advance(c2, n_pass, nJ, first);                                                       \
         }
     // whole pairs of steps without any skip path inside the loop (a skipped step would leave its
     // predecessor's prefetch pending on the back edge: static s_waitcnt vmcnt(0)); then the odd tail
