@@ -25,7 +25,7 @@ def test_grid_and_folds_match_real_r(golden, yeast):
 def test_cells_match_real_r(golden, yeast):
     """18 fits (6 cells x 3 folds) spread over the grid, fold SSE vs Results.Detail$MSE.
     (The full 1200-fit table is tools/yeast_full_table.py; its round-1 report is
-    profiles/r01/yeast_full_table_vs_real_R_v11.json: 1184 fits agree to < 1e-9, the other 16 -- all at
+    profiles/r01/yeast_full_table_vs_real_R_v14.json: 1184 fits agree to < 1e-9, the other 16 -- all at
     alpha = 1 with transient active sets of 440-870 and up to 10010 inner iterations -- differ by
     4e-6 ... 3e-3 because their trajectories amplify summation-order rounding; (alpha*, lambda*) equal.)"""
     G, y = yeast
