@@ -184,29 +184,6 @@ DEV void fs_step(gptr_cc Sig, gptr_cc G, lptr_cull loff, lptr_d lmu, lptr_d acur
 {
     constexpr int NX = CUR ^ 1;
     const int l15 = lane & 15, l4 = lane >> 4;
-    // ---- requests: this wave's share of the Sigma panels of step g+2 ...
-    {
-        const unsigned lane_off = (unsigned)((l4 * ld + l15) * 8);
-#pragma unroll
-        for (int pi = 0; pi < FS_PPW; pi++) {
-            const int t2 = wave + pi * FS_NWAVES, J = fs_pass_begin(c2.pass, first) + t2;
-            const bool on = J < fs_pass_end(c2.pass, first) && c2.h <= J;
-            const unsigned o = on ? (unsigned)((c2.h * 16 * ld + J * 16) * 8) + lane_off : 0u;
-            const unsigned st = on ? (unsigned)(4 * ld * 8) : 0u;
-#pragma unroll
-            for (int s = 0; s < 4; s++) pa[CUR][pi][s] = *(gptr_cd)(Sig + (o + s * st));
-        }
-    }
-    // ... and its own Gram operands of step g+1
-#pragma unroll
-    for (int s = 0; s < 4; s++) {
-        const unsigned long long ro = loff[c1.h * 16 + 4 * s + l4];
-#pragma unroll
-        for (int nb = 0; nb < FS_NB; nb++) {
-            const int i = c1.i0 + 16 * (wave + nb * FS_NWAVES) + l15;
-            bvr[NX][nb][s] = *(gptr_cd)(G + (ro + (unsigned)((i < K ? i : K - 1) * 8)));
-        }
-    }
     // ---- matrix ops of step g; rows beyond the active set contribute zero
     const int jb = fs_pass_begin(c0.pass, first), je = fs_pass_end(c0.pass, first);
     double bv[FS_NB][4];
@@ -233,6 +210,32 @@ DEV void fs_step(gptr_cc Sig, gptr_cc G, lptr_cull loff, lptr_d lmu, lptr_d acur
         if (t + FS_APRE < FS_TPP) {
 #pragma unroll
             for (int s = 0; s < 4; s++) an[t % FS_APRE][s] = acur[((t + FS_APRE) * 4 + s) * 64 + lane];
+        }
+        // ---- requests, placed behind work that is already queued so that their address arithmetic and the LDS read of
+        // the row offsets do not hold up the first matrix ops of the step: this wave's share of the Sigma panels of
+        // step g+2 in front of tile 0 ...
+        if (t == 0) {
+            const unsigned lane_off = (unsigned)((l4 * ld + l15) * 8);
+#pragma unroll
+            for (int pi = 0; pi < FS_PPW; pi++) {
+                const int t2 = wave + pi * FS_NWAVES, J2 = fs_pass_begin(c2.pass, first) + t2;
+                const bool on = J2 < fs_pass_end(c2.pass, first) && c2.h <= J2;
+                const unsigned o = on ? (unsigned)((c2.h * 16 * ld + J2 * 16) * 8) + lane_off : 0u;
+                const unsigned st = on ? (unsigned)(4 * ld * 8) : 0u;
+#pragma unroll
+                for (int s = 0; s < 4; s++) pa[CUR][pi][s] = *(gptr_cd)(Sig + (o + s * st));
+            }
+        }
+        if (t == 1) {                                         // ... and its own Gram operands of step g+1 behind tile 0's matrix ops
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const unsigned long long ro = loff[c1.h * 16 + 4 * s + l4];
+#pragma unroll
+                for (int nb = 0; nb < FS_NB; nb++) {
+                    const int i = c1.i0 + 16 * (wave + nb * FS_NWAVES) + l15;
+                    bvr[NX][nb][s] = *(gptr_cd)(G + (ro + (unsigned)((i < K ? i : K - 1) * 8)));
+                }
+            }
         }
         if (J < je && c0.h <= J) {
 #pragma unroll
