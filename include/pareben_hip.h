@@ -102,6 +102,13 @@ int pareben_ctx_last_timing(pareben_ctx *ctx, double ms[3]);
  * info[2] active-set capacity, info[3] workspace bytes per workgroup (low 31 bits in KiB). */
 int pareben_ctx_launch_info(pareben_ctx *ctx, int64_t info[4]);
 
+/* Test hook: run the per-fold preparation kernels and copy the normalised Gram matrix of fold
+ * `fold` (0-based) to `out` (K x K doubles, out[u*K + i] = x_i.(x_u/|x_u|)/|x_i| over the fold's training
+ * rows: row u is the reference's BASIS_PHI row of basis u, elasticNetLinearNeMainEff.c:1608-1630), K = p or
+ * p(p+1)/2 with epistasis.  PAREBEN_EINVAL for the binomial prior or when the context keeps Gram rows on
+ * demand instead of whole matrices. */
+int pareben_ctx_gram(pareben_ctx *ctx, int fold, double *out);
+
 int pareben_ctx_destroy(pareben_ctx *ctx);
 
 /* One-shot convenience: create + run + destroy. */

@@ -5,7 +5,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpareben_hip.so")
+# PAREBEN_LIB=<path> loads another build of the same library (A/B timing of kernel variants, diagnostic builds)
+LIB_PATH = os.environ.get("PAREBEN_LIB") or os.path.join(_HERE, "lib", "libpareben_hip.so")
 NCOUNTERS = 12
 COUNTER_NAMES = ("n_outer", "n_inner", "n_add", "n_del", "n_reest", "n_fullstat", "sum_m_action",
                  "sum_m_full", "sum_m2_full", "m_final", "m_max", "status")
@@ -37,6 +38,7 @@ def load():
     L.pareben_ctx_last_timing.argtypes = [C.c_void_p, dp]
     L.pareben_ctx_launch_info.argtypes = [C.c_void_p, lp]
     L.pareben_ctx_destroy.argtypes = [C.c_void_p]
+    L.pareben_ctx_gram.argtypes = [C.c_void_p, C.c_int, dp]
     L.pareben_cv_grid.argtypes = [dp, C.c_int, C.c_int, dp, ip, C.c_int, dp, dp, C.c_int, C.c_int, C.c_int, C.c_int, dp, ip, lp]
     L.pareben_fit_gaussian.argtypes = [dp, dp, C.c_double, C.c_double, dp, dp, dp, C.c_int, C.c_int, C.c_int, dp, C.c_int, lp]
     L.pareben_fit_gaussian_epis.argtypes = L.pareben_fit_gaussian.argtypes
@@ -74,6 +76,7 @@ class Context:
             raise ValueError("BASIS must be n x p and Target / fold_id must have n entries")
         self.n, self.p = X.shape
         self.n_folds = int(n_folds)
+        self.epis = bool(epis)
         self._h = C.c_void_p()
         _chk(L.pareben_ctx_create(C.byref(self._h), int(device), _dp(X), self.n, self.p, _dp(y), _ip(fid), self.n_folds,
                                   0 if prior == "gaussian" else 1, 1 if epis else 0, int(max_active)), "pareben_ctx_create")
@@ -90,6 +93,13 @@ class Context:
         _chk(L.pareben_ctx_run(self._h, nc, _dp(alpha), _dp(lam), _dp(err), _ip(st),
                                _lp(cnt) if cnt is not None else None), "pareben_ctx_run")
         return err, st, cnt
+
+    def gram(self, fold):
+        """Test hook (pareben_ctx_gram): normalised Gram matrix of 0-based fold `fold`, [K, K], row u = Gram row of basis u."""
+        k = self.p * (self.p + 1) // 2 if self.epis else self.p
+        out = np.empty((k, k))
+        _chk(load().pareben_ctx_gram(self._h, int(fold), _dp(out)), "pareben_ctx_gram")
+        return out
 
     def last_timing(self):
         ms = np.zeros(3)

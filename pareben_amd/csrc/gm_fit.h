@@ -163,8 +163,8 @@ DEV void fs_advance(FsCur &c, int n_pass, int nJ, int first)
 // consecutive features of one Gram row per 16 lanes, i.e. whole 128-byte lines -- and a wave needs only its
 // own column blocks, so the Gram block is not shared through LDS at all: each wave loads its operands for
 // step g+1 straight into a register ring during step g (loff[p] = byte offset of Gram row p of the active
-// set).  Rows >= M are zeroed when they are used, so Sigma entries beyond the active block (finite: the
-// workspace is zero-initialised) contribute 0.
+// set).  Rows >= M are zeroed when they are used, and the Sigma panels are staged with exact zeros outside
+// the active block, so nothing the workspace holds beyond it (stale values of earlier fits) reaches a result.
 // Sigma is symmetric: row tile J only visits k-blocks h <= J and counts h < J twice (the panel is
 // doubled when it is staged; doubling is exact).
 // When h == J the k-block on the diagonal IS tile J's own rows, and the rows a lane holds as B operand
@@ -264,10 +264,14 @@ DEV void fs_step(gptr_cc Sig, gptr_cc G, lptr_cull loff, lptr_d lmu, lptr_d acur
     for (int pi = 0; pi < FS_PPW; pi++) {
         const int t = wave + pi * FS_NWAVES, J = fs_pass_begin(c1.pass, first) + t;
         const double w = c1.h < J ? 2.0 : 1.0;
+        const bool row_in = J * 16 + l15 < M;
 #pragma unroll
         for (int s = 0; s < 4; s++) {
             double v = pa[NX][pi][s] * w;
             asm volatile("" : "+v"(v));                        // consume the load on every path (see above)
+            // entries of the ragged 16-block beyond the active set are staged as exact zeros whatever the
+            // workspace holds there (a previous fit of this workgroup may have left non-finite values)
+            if (!(row_in && c1.h * 16 + 4 * s + l4 < M)) v = 0.0;
             if (J < fs_pass_end(c1.pass, first) && c1.h <= J) anxt[(t * 4 + s) * 64 + lane] = v;
         }
     }
@@ -364,7 +368,7 @@ DEVNI void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W,
             for (int s = 0; s < 4; s++) {
                 const double v0 = *(gptr_cd)(Sig + (o0 + s * st0));
                 pa[1][pi][s] = *(gptr_cd)(Sig + (o1 + s * st1));
-                if (on0) la[(t * 4 + s) * 64 + lane] = v0 * (0 < t ? 2.0 : 1.0);
+                if (on0) la[(t * 4 + s) * 64 + lane] = (t * 16 + l15 < M && 4 * s + l4 < M) ? v0 * (0 < t ? 2.0 : 1.0) : 0.0;
             }
         }
     }

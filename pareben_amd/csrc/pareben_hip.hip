@@ -23,6 +23,9 @@
 #define FIT_THREADS 512          // 8 wavefronts per fit workgroup: 256 VGPRs per lane for the matrix-core pass
 #endif
 #define FS_NWAVES (FIT_THREADS / 64)
+#ifndef FIT_WAVES_PER_EU
+#define FIT_WAVES_PER_EU 2       // wavefronts per SIMD the fit kernels are compiled for (register budget 512 / this)
+#endif
 
 #include "../../include/pareben_hip.h"
 #include "types.h"
@@ -137,55 +140,139 @@ __global__ void ystats_kernel(const double *__restrict__ y, int N, double *__res
     if (threadIdx.x == 0) { out[0] = m; out[1] = v / (N - 1); }
 }
 
-// G[u*K + i] = ( sum_h X[h,i] * (X[h,u] * rscale[u]) ) / scale[i].  64 x 64 output tile per
-// 256-thread workgroup, 4 x 4 register tile per thread, 16-deep K-slabs staged through LDS.
-#define GT 64
-#define GK 16
-__global__ __launch_bounds__(256) void gram_kernel(const double *__restrict__ X, int N, int K,
-                                                   const double *__restrict__ scale,
-                                                   const double *__restrict__ rscale,
-                                                   double *__restrict__ G)
+// Normalised Gram matrix of one fold: G[u*K + i] = D[u][i] * rscale[u] / scale[i] with D = X'X, i.e. the
+// reference's BASIS_PHI row of basis u (x_i . (x_u/|x_u|) / |x_i|, elasticNetLinearNeMainEff.c:1171-1177,
+// :1608-1630) for every u at once.  D is symmetric, so only the blocks on and below the diagonal are
+// computed (half of the 2 N K^2 flops) and each is stored twice with its own scaling.
+//   * FP64 matrix cores: a 128 x 128 block per 256-thread workgroup, 64 x 64 per wave = 4 x 4 accumulator
+//     tiles of v_mfma_f64_16x16x4_f64 (A rows <-> u, B columns <-> i, k <-> sample h).  A tile's sum is one
+//     fma chain over h ascending (the matrix op rounds like four chained fmas, tools/ubench/mfma_f64_order.hip),
+//     so D[u][i] == D[i][u] bit for bit and the values do not depend on the tiling.
+//   * Operands: 16-sample slabs of the two 128-column panels, loaded with 16 lanes along h (columns are
+//     contiguous in h: whole 128-byte lines), staged in LDS as [column][h] with pitch 17 and double
+//     buffered: the loads of slab s+1 are in flight while slab s feeds the matrix cores; one barrier per slab.
+//     Per slab and workgroup: 32 KB loaded for 0.5 MFLOP -> far from any memory bound once the panels of
+//     concurrently running blocks come out of L2.
+//   * XCD-aware block order: workgroup b runs on XCD b % 8, which is given a contiguous range of the
+//     row-major lower-triangle block list, so the 32 CUs of an XCD work on consecutive blocks of one block
+//     row at any time (one shared u-panel, neighbouring i-panels) and their panels meet in that XCD's L2.
+//   * Mirror store: each 16 x 16 tile is transposed through a wave-private LDS patch so that both copies
+//     leave as 128-byte row segments.
+#define GB 128
+#define GS 16
+#define GP 17
+typedef double gd4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256, 2) void gram_kernel(const double *__restrict__ X, int N, int K,
+                                                      const double *__restrict__ scale,
+                                                      const double *__restrict__ rscale,
+                                                      double *__restrict__ G, int nb, int n_blocks)
 {
-    __shared__ double sI[GK][GT + 1];
-    __shared__ double sU[GK][GT + 1];
-    const int i0 = blockIdx.x * GT, u0 = blockIdx.y * GT;
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;    // tx -> i, ty -> u
-    double acc[4][4];
+    __shared__ double sm[2][2][GB * GP];
+    const int per = (n_blocks + 7) / 8;
+    const int lin = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (lin >= n_blocks) return;                                  // uniform per workgroup, before any barrier
+    (void)nb;
+    int bu = (int)((sqrt(8.0 * (double)lin + 1.0) - 1.0) * 0.5);
+    while ((long long)(bu + 1) * (bu + 2) / 2 <= lin) bu++;
+    while ((long long)bu * (bu + 1) / 2 > lin) bu--;
+    const int bi = lin - (int)((long long)bu * (bu + 1) / 2);     // bi <= bu
+    const bool diag = bu == bi;
+    const int u0 = bu * GB, i0 = bi * GB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int wu = wave >> 1, wi = wave & 1;
+    // staging: thread -> sample h = tid & 15 of columns (tid >> 4) + 16 q
+    const int sh = tid & 15, sc = tid >> 4;
+    gd4 acc[4][4];
 #pragma unroll
     for (int a = 0; a < 4; a++)
 #pragma unroll
-        for (int b = 0; b < 4; b++) acc[a][b] = 0;
-    for (int h0 = 0; h0 < N; h0 += GK) {
-        // 64 columns x 16 rows per operand = 1024 elements, 4 per thread; consecutive threads
-        // read consecutive h of one column (columns are contiguous in h)
-        for (int e = threadIdx.x; e < GT * GK; e += 256) {
-            const int c = e / GK, h = e % GK;
-            const int hh = h0 + h;
-            const int ci = i0 + c, cu = u0 + c;
-            sI[h][c] = (hh < N && ci < K) ? X[(size_t)ci * N + hh] : 0.0;
-            sU[h][c] = (hh < N && cu < K) ? X[(size_t)cu * N + hh] * rscale[cu] : 0.0;
+        for (int b = 0; b < 4; b++) acc[a][b] = gd4{0, 0, 0, 0};
+    double ra[8], rb[8];
+    auto fetch = [&](int h0) {
+        const int hh = h0 + sh;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int cu = u0 + sc + 16 * q, ci = i0 + sc + 16 * q;
+            ra[q] = (hh < N && cu < K) ? X[(size_t)cu * N + hh] : 0.0;
+            rb[q] = (!diag && hh < N && ci < K) ? X[(size_t)ci * N + hh] : 0.0;
         }
-        __syncthreads();
+    };
+    auto stash = [&](int buf) {
 #pragma unroll
-        for (int h = 0; h < GK; h++) {
-            double vi[4], vu[4];
+        for (int q = 0; q < 8; q++) {
+            sm[buf][0][(sc + 16 * q) * GP + sh] = ra[q];
+            if (!diag) sm[buf][1][(sc + 16 * q) * GP + sh] = rb[q];
+        }
+    };
+    const int n_slab = (N + GS - 1) / GS;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int s = 0; s < n_slab; s++) {
+        const int buf = s & 1;
+        if (s + 1 < n_slab) fetch((s + 1) * GS);
+        const double *pa = &sm[buf][0][(wu * 64 + l15) * GP + l4];
+        const double *pb = &sm[buf][diag ? 0 : 1][(wi * 64 + l15) * GP + l4];
 #pragma unroll
-            for (int a = 0; a < 4; a++) { vi[a] = sI[h][tx + 16 * a]; vu[a] = sU[h][ty + 16 * a]; }
+        for (int ks = 0; ks < GS / 4; ks++) {
+            double av[4], bv[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) { av[t] = pa[t * 16 * GP + ks * 4]; bv[t] = pb[t * 16 * GP + ks * 4]; }
 #pragma unroll
             for (int a = 0; a < 4; a++)
 #pragma unroll
-                for (int b = 0; b < 4; b++) acc[a][b] += vu[a] * vi[b];
+                for (int b = 0; b < 4; b++) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
         }
+        if (s + 1 < n_slab) stash(buf ^ 1);
         __syncthreads();
     }
+    // direct copy: rows u, 16 consecutive i per 16 lanes
+    double sci[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const int i = i0 + wi * 64 + b * 16 + l15;
+        sci[b] = i < K ? scale[i] : 1.0;
+    }
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int u = u0 + wu * 64 + a * 16 + l4 + 4 * r;
+            if (u >= K) continue;
+            const double rs = rscale[u];
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int i = i0 + wi * 64 + b * 16 + l15;
+                if (i < K) G[(size_t)u * K + i] = acc[a][b][r] * rs / sci[b];
+            }
+        }
+    if (diag) return;                                             // the full block was computed: both triangles are stored
+    // mirrored copy G[i][u] = D[u][i] * rscale[i] / scale[u]: tile transposed through a wave-private patch
+    double *patch = &sm[0][0][0] + wave * (16 * GP);
 #pragma unroll
     for (int a = 0; a < 4; a++) {
-        const int u = u0 + ty + 16 * a;
-        if (u >= K) continue;
+        const int u = u0 + wu * 64 + a * 16 + l15;               // after the transpose a lane holds row u = l15 of the tile
+        const double scu = u < K ? scale[u] : 1.0;
 #pragma unroll
         for (int b = 0; b < 4; b++) {
-            const int i = i0 + tx + 16 * b;
-            if (i < K) G[(size_t)u * K + i] = acc[a][b] / scale[i];
+#pragma unroll
+            for (int r = 0; r < 4; r++) patch[(l4 + 4 * r) * GP + l15] = acc[a][b][r];      // [row u][col i]
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int ic = l4 + 4 * r;                         // column of the tile = feature i
+                const int i = i0 + wi * 64 + b * 16 + ic;
+                const double d = patch[l15 * GP + ic];             // D[u = l15][i = ic]
+                if (u < K && i < K) G[(size_t)i * K + u] = d * rscale[i] / scu;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
 }
@@ -301,7 +388,9 @@ struct CvParams {
 
 // LDS carve of one fit workgroup (dynamic shared memory): a phase-local pool (full-stat Gram
 // k-blocks and Sigma panels / inverse panels / action vectors) and the small reduction scratch.
+#ifndef LDS_POOL_DOUBLES
 #define LDS_POOL_DOUBLES 16384
+#endif
 #define LDS_FIT_BYTES ((LDS_POOL_DOUBLES + 2 * BLK_MAX_WAVES) * 8 + 4 * BLK_MAX_WAVES * 4)
 extern __shared__ double lds_dyn[];
 
@@ -403,7 +492,7 @@ __device__ void fs_help_loop(const Blk &B, const FsShare &sh, int K, bool until_
     }
 }
 
-__global__ __launch_bounds__(FIT_THREADS) void gm_cv_kernel(CvParams P)
+__global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_EU) void gm_cv_kernel(CvParams P)
 {
     __shared__ int s_unit;
     __shared__ FitCounters s_cnt;
@@ -470,7 +559,7 @@ struct BmCvParams {
     long long *phase;      // [n_units x PH_N] diagnostic ticks, may be null
 };
 
-__global__ __launch_bounds__(FIT_THREADS) void bm_cv_kernel(BmCvParams P)
+__global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_EU) void bm_cv_kernel(BmCvParams P)
 {
     __shared__ int s_unit;
     __shared__ FitCounters s_cnt;
@@ -527,7 +616,7 @@ struct FitParams {
 // single Gaussian fit with the reference's .C outputs: elasticNetLinearNeMainEff.c:199-227 (Beta K x 4:
 // locus, locus, effect, posterior variance) or elasticNetLinearNeFull2.c:115-134, :232-238 (Beta
 // M_full x 5: locus1, locus2, effect, variance, 1-based column id of used columns)
-__global__ __launch_bounds__(FIT_THREADS) void gm_fit_kernel(FitParams P)
+__global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_EU) void gm_fit_kernel(FitParams P)
 {
     __shared__ FitCounters s_cnt;
     __shared__ long long s_ph[PH_N];
@@ -586,7 +675,7 @@ struct BmFitParams {
 };
 
 // single binomial fit with the reference's .C outputs (ElasticNetBinaryNEmainEff.c:346-389)
-__global__ __launch_bounds__(FIT_THREADS) void bm_fit_kernel(BmFitParams P)
+__global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_EU) void bm_fit_kernel(BmFitParams P)
 {
     __shared__ FitCounters s_cnt;
     __shared__ long long s_ph[PH_N];
@@ -822,9 +911,11 @@ static int prepare_folds(pareben_ctx *c)
         if (H.nte) hipLaunchKernelGGL(gather_kernel, dim3((H.nte + 255) / 256), dim3(256), 0, c->stream, c->d_y, H.d_te, H.nte, H.yte);
         hipLaunchKernelGGL(colstats_kernel, dim3(kf), dim3(256), 0, c->stream, H.X, H.y, H.N, H.scale, H.rscale, H.bt0, H.cs);
         hipLaunchKernelGGL(ystats_kernel, dim3(1), dim3(256), 0, c->stream, H.y, H.N, H.ystat);
-        if (H.G) {
-            dim3 gg((kf + GT - 1) / GT, (kf + GT - 1) / GT);
-            hipLaunchKernelGGL(gram_kernel, gg, dim3(256), 0, c->stream, H.X, H.N, kf, H.scale, H.rscale, H.G);
+        if (H.G) {                                  // lower-triangle blocks, dealt to the XCDs in contiguous ranges
+            const int nb = (kf + GB - 1) / GB;
+            const long long nbl = (long long)nb * (nb + 1) / 2;
+            const int per = (int)((nbl + 7) / 8);
+            hipLaunchKernelGGL(gram_kernel, dim3(per * 8), dim3(256), 0, c->stream, H.X, H.N, kf, H.scale, H.rscale, H.G, nb, (int)nbl);
         }
         // ymean / varY live inside the FoldDev record: copy the two doubles device-to-device
         HIPCHK(hipMemcpyAsync((char *)(c->d_folds + f) + offsetof(FoldDev, ymean), H.ystat, 2 * sizeof(double),
@@ -853,9 +944,12 @@ static int ensure_workspace(pareben_ctx *c, int blocks)
         if (c->d_ws) { hipFree(c->d_ws); c->d_ws = nullptr; c->ws_bytes = 0; }
         hipError_t e = hipMalloc((void **)&c->d_ws, need);
         if (e != hipSuccess) return fail(PAREBEN_ENOMEM, "workspace hipMalloc", e);
-        // zero once: the matrix-core full-stat pass reads (and multiplies by exact zeros) Sigma
-        // entries just outside the active block, which must therefore be finite
-        e = hipMemset(c->d_ws, 0, need);
+        // Every fit initialises what it reads (the matrix-core passes mask the ragged 16-blocks beyond the
+        // active set), so the fill value is irrelevant to the results; zero for reproducible memory dumps.
+        // PAREBEN_WS_POISON=1 fills with 0xFF bytes (NaN doubles, -1 ints) instead:
+        // tests/test_hip_parity.py::test_poisoned_workspace_is_bit_identical proves that independence.
+        const char *poison = getenv("PAREBEN_WS_POISON");
+        e = hipMemset(c->d_ws, (poison && atoi(poison)) ? 0xFF : 0, need);
         if (e != hipSuccess) return fail(PAREBEN_EHIP, "workspace hipMemset", e);
         c->ws_bytes = need;
     }
@@ -987,6 +1081,23 @@ extern "C" int pareben_ctx_run(pareben_ctx *c, int n_cells, const double *alpha,
     return PAREBEN_OK;
 }
 
+extern "C" int pareben_ctx_gram(pareben_ctx *c, int fold, double *out)
+{
+    if (!c || !out || fold < 0 || fold >= c->n_folds) return fail(PAREBEN_EINVAL, "bad argument");
+    if (c->prior != PAREBEN_PRIOR_GAUSSIAN || c->lazy || !c->folds[fold].G) return fail(PAREBEN_EINVAL, "this context holds no whole Gram matrices");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipEventRecord(c->ev[0], c->stream));
+    const int rc = prepare_folds(c);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(c->ev[1], c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    float a = 0;
+    HIPCHK(hipEventElapsedTime(&a, c->ev[0], c->ev[1]));
+    c->last_ms[0] = a; c->last_ms[1] = 0; c->last_ms[2] = a;
+    HIPCHK(hipMemcpy(out, c->folds[fold].G, sizeof(double) * (size_t)c->kfull * c->kfull, hipMemcpyDeviceToHost));
+    return PAREBEN_OK;
+}
+
 extern "C" int pareben_ctx_last_timing(pareben_ctx *c, double ms[3])
 {
     if (!c || !ms) return fail(PAREBEN_EINVAL, "bad argument");
@@ -1110,7 +1221,7 @@ extern "C" int pareben_fit_binomial(const double *basis, const double *target, d
 // Diagnostic build only (-DPAREBEN_DIAG, tools/ubench/fullstat_rate.py): time the full-stat feature
 // pass alone on `blocks` workgroups, each with its own Sigma (cap x cap) and a shared M x K Gram.
 struct DiagParams { const double *G; char *ws; size_t stride, offK, offSig, offM; int K, cap, M, reps; };
-__global__ __launch_bounds__(FIT_THREADS) void diag_fullstat_kernel(DiagParams P)
+__global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_EU) void diag_fullstat_kernel(DiagParams P)
 {
     const Blk B = make_blk();
     GmWork W = ws_carve(P.ws + (size_t)blockIdx.x * P.stride, P.K, P.cap, P.offK, P.offSig, P.offM);

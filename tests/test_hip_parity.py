@@ -104,6 +104,74 @@ def test_rerun_is_bit_identical_and_order_free(golden):
     assert np.array_equal(E3, E1[perm])
 
 
+def test_gram_kernel_vs_numpy(golden):
+    """gram_kernel (FP64 matrix cores, lower-triangle blocks + mirrored store) against numpy.
+    Integer-valued designs (BASIS is {-1, 0, 1}): X'X is exact, so G[u][i] = D * (1/|x_u|) / |x_i| must
+    agree bit for bit.  Gaussian design with ragged sizes (K not a multiple of the 128-block, N not a
+    multiple of the 16-sample slab): to rounding, and exactly symmetric before scaling."""
+    X = golden.BASIS[:, :481]
+    g = golden.basis481
+    fid = g["fold_id"]
+    with pareben_amd.Context(X, golden.y, fid, 5) as ctx:
+        for f in (0, 4):
+            Gd = ctx.gram(f)
+            Xt = X[fid != f + 1]
+            q = np.sum(Xt * Xt, axis=0); q[q == 0] = 1.0
+            sc = np.sqrt(q)
+            D = Xt.T @ Xt                                           # exact in float64 (small integers)
+            want = (D * (1.0 / sc)[:, None]) / sc[None, :]
+            assert np.array_equal(Gd, want)
+    rng = np.random.default_rng(2)
+    n, p = 203, 333
+    Xg = np.asfortranarray(rng.standard_normal((n, p)))
+    Xg[:, 7] = 0.0
+    fid = AssignToFolds(Xg, 3)
+    with pareben_amd.Context(Xg, rng.standard_normal(n), fid, 3) as ctx:
+        Gd = ctx.gram(1)
+    Xt = Xg[fid != 2]
+    q = np.sum(Xt * Xt, axis=0); q[q == 0] = 1.0
+    sc = np.sqrt(q)
+    want = (Xt.T @ Xt) / sc[:, None] / sc[None, :]
+    assert np.abs(Gd - want).max() < 1e-13
+    Dd = Gd * sc[:, None] * sc[None, :]
+    assert np.abs(Dd - Dd.T).max() < 1e-12 * np.abs(Dd).max()
+    assert np.all(Gd[7] == 0) and np.all(Gd[:, 7] == 0)
+
+
+def test_poisoned_workspace_is_bit_identical(golden, monkeypatch):
+    """Every fit is self-contained: nothing a previous fit of the same workgroup (or hipMalloc) left in
+    the workspace may reach a result.  PAREBEN_WS_POISON=1 fills the fit workspaces with 0xFF bytes (NaN
+    doubles, -1 ints) instead of zeros; a NaN just outside the active block would turn every S_in / Q_in of
+    the matrix-core full-stat pass into NaN if the ragged 16-blocks were not masked.  Gaussian (active sets
+    up to ~240, i.e. many ragged block shapes), epistasis and binomial workspaces."""
+    g = golden.basis481
+    g4 = golden.config4
+    Xb, yb = golden.BASISbinomial[:300, :120], golden.yBinomial[:300]
+    fb = AssignToFolds(Xb, 3)
+    ab, lb = BuildGrid(Xb, yb, 3)
+    selb = np.arange(0, 400, 13)
+
+    def run_all():
+        with pareben_amd.Context(golden.BASIS, golden.y, g["fold_id"], 5) as ctx:
+            r1 = ctx.run(g["alpha"], g["lam"])
+            r1b = ctx.run(g["alpha"][::-1].copy(), g["lam"][::-1].copy())      # second launch on the used workspace
+        with pareben_amd.Context(golden.BASIS[:200, :60], g4["y_scaled"], g4["fold_id"], 5, epis=True) as ctx:
+            r2 = ctx.run(g4["alpha_scaled"], g4["lam_scaled"])
+        with pareben_amd.Context(Xb, yb, fb, 3, prior="binomial") as ctx:
+            r3 = ctx.run(ab[selb], lb[selb])
+        return r1, r1b, r2, r3
+
+    clean = run_all()
+    monkeypatch.setenv("PAREBEN_WS_POISON", "1")
+    dirty = run_all()
+    for (Ec, sc, cc), (Ed, sd, cd) in zip(clean, dirty):
+        assert np.array_equal(sc, sd)
+        assert np.array_equal(Ec, Ed, equal_nan=True)
+        assert np.array_equal(cc, cd)
+    assert np.array_equal(clean[0][0], clean[1][0][::-1])
+    assert _rel(clean[0][0], g["fold_err"]).max() < REL_FOLD
+
+
 def test_edge_cases(oracle):
     rng = np.random.default_rng(11)
     X = np.asfortranarray(rng.standard_normal((41, 17)))
