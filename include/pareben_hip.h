@@ -42,14 +42,15 @@ extern "C" {
 #define PAREBEN_PRIOR_BINOMIAL 1
 
 /* per-fit status bits written to status[] */
-#define PAREBEN_ST_OVERFLOW 1     /* active set reached the workspace capacity       */
+#define PAREBEN_ST_OVERFLOW 1     /* active set grew past the reference's basisMax; with ST_ABORT: past the workspace too */
 #define PAREBEN_ST_CHOLESKY 2     /* Hessian not positive definite                   */
 #define PAREBEN_ST_STALE    4     /* reference's stale-slot delete path was taken    */
 #define PAREBEN_ST_ABORT    8     /* fit stopped early; its fold_err entry is NaN     */
 
 /* number of int64 counters per fit in counters[] (order: n_outer, n_inner, n_add, n_del,
- * n_reest, n_fullstat, sum_m_action, sum_m_full, sum_m2_full, m_final, m_max, status) */
-#define PAREBEN_NCOUNTERS 12
+ * n_reest, n_fullstat, sum_m_action, sum_m_full, sum_m2_full, m_final, m_max, status, mfma_tiles =
+ * 16x16x16 tile products (8192 flop each) executed on the FP64 matrix cores for this fit) */
+#define PAREBEN_NCOUNTERS 13
 
 typedef struct pareben_ctx pareben_ctx;
 
@@ -63,8 +64,12 @@ int pareben_device_count(void);
  * what R/AssignToFolds.R:6-19 returns).  prior: gaussian (elasticNetLinearNeMainEff.c /
  * elasticNetLinearNeFull2.c) or binomial (ElasticNetBinaryNEmainEff.c).  epis: 0 = main effects,
  * 1 = add the p(p-1)/2 pairwise columns x_i*x_j in the reference's order (gaussian only).
- * max_active <= 0 picks the default active-set capacity min(p, 1e7/p, 2048) (the reference's
- * basisMax, elasticNetLinearNeMainEff.c:68-69, bounded).  The context owns every device buffer.
+ * Active-set capacity.  The reference sizes its arrays for basisMax = min(p, 1e7/p) columns
+ * (elasticNetLinearNeMainEff.c:68-69; elasticNetLinearNeFull2.c:67-80 with epistasis) and runs off them when
+ * a fit grows past that (:605-611: it prints "out of Memory" and continues).  Here such a fit is FLAGGED
+ * (PAREBEN_ST_OVERFLOW) and continues in a workspace of max(basisMax, min(N_train, 1024)) columns (bounded by
+ * p and 2048); only there it is stopped (PAREBEN_ST_OVERFLOW | PAREBEN_ST_ABORT, score NaN).  max_active > 0
+ * lowers both limits; <= 0 picks the defaults.  The context owns every device buffer.
  */
 int pareben_ctx_create(pareben_ctx **out, int device,
                        const double *basis, int n, int p, const double *target,
@@ -99,8 +104,9 @@ int pareben_ctx_run(pareben_ctx *ctx, int n_cells, const double *alpha, const do
 int pareben_ctx_last_timing(pareben_ctx *ctx, double ms[3]);
 
 /* Geometry of the last launch: info[0] workgroups, info[1] threads per workgroup,
- * info[2] active-set capacity, info[3] workspace bytes per workgroup (low 31 bits in KiB). */
-int pareben_ctx_launch_info(pareben_ctx *ctx, int64_t info[4]);
+ * info[2] active-set capacity of the workspaces, info[3] workspace KiB per workgroup,
+ * info[4] the reference's basisMax (fits growing past it carry PAREBEN_ST_OVERFLOW). */
+int pareben_ctx_launch_info(pareben_ctx *ctx, int64_t info[5]);
 
 /* Test hook: run the per-fold preparation kernels and copy the normalised Gram matrix of fold
  * `fold` (0-based) to `out` (K x K doubles, out[u*K + i] = x_i.(x_u/|x_u|)/|x_i| over the fold's training

@@ -38,6 +38,7 @@ typedef struct {
 typedef struct {
     gm_variant v;
     int N, K, cap;
+    int cap_ref;               /* the reference's basisMax (<= cap); see eben_set_capacity_policy */
     const double *X, *y;
     double lambda, alpha;
     double *scale;             /* K   column norms (1 if zero)                    */
@@ -438,6 +439,7 @@ static int gm_inner(gm *s, int iter, double residual, double varY, double *cs, d
                     upd = 1;
                 } else if (sel == ACT_ADD) {
                     if (s->M + 1 > s->cap) { s->c.status |= 1; free(phi); free(e); return 1; }
+                    if (s->M + 1 > s->cap_ref) s->c.status |= 1;   /* flag-and-continue policy of the build under test */
                     s->c.n_add++; s->c.sum_m_action += s->M;
                     gm_add(s, nu, newA, phi);
                     upd = 1;
@@ -500,7 +502,36 @@ static int gm_inner(gm *s, int iter, double residual, double varY, double *cs, d
 
 /* shared driver: X is the (possibly expanded) N x K design; scale[] as the variant defines it.
  * Outputs in model space: *M_out, used[], mu[]/scale and Sigma_ii/scale^2 through the callback arrays. */
-static int gm_core(const gm_variant *v, const double *X, const double *y, int N, int K, int cap, const double *scale_in,
+/* Capacity policy.  Default = the reference's: the arrays hold basisMax columns and a fit that needs more is
+ * stopped (the reference itself prints "out of Memory" and runs off its arrays, MainEff.c:605-611).  The HIP
+ * build instead FLAGS such a fit (status bit 0) and lets it continue in a workspace of max(basisMax,
+ * min(N, 1024)) columns; eben_set_capacity_policy(1, r) makes the oracle do the same so that those fits can be
+ * compared too; r > 0 lowers basisMax to r (PAREBEN_REF_CAP on the other side), which brings the
+ * flag-and-continue path within reach of small test problems. */
+static int g_continue_past_ref = 0, g_ref_cap_override = 0;
+void eben_set_capacity_policy(int continue_past_basismax, int ref_cap_override)
+{
+    g_continue_past_ref = continue_past_basismax;
+    g_ref_cap_override = ref_cap_override;
+}
+static void capacities(int ref_rule, long K, int N, int *cap_ref, int *cap)
+{
+    long ref = ref_rule;
+    if (ref > K) ref = K;
+    long c = ref;
+    if (g_continue_past_ref) {
+        long lim = N < 1024 ? N : 1024;
+        if (lim > c) c = lim;
+        if (c > K) c = K;
+        if (c > 2048) c = 2048;
+        if (c < 2) c = 2;
+        if (g_ref_cap_override > 0 && g_ref_cap_override < ref) ref = g_ref_cap_override;
+        if (ref > c) ref = c;
+    }
+    *cap_ref = (int)ref; *cap = (int)c;
+}
+
+static int gm_core(const gm_variant *v, const double *X, const double *y, int N, int K, int cap, int cap_ref, const double *scale_in,
                    double lambda, double alpha, int *M_out, int *used_out, double *w_out, double *var_out,
                    double *wald, double *intercept, double *residual, eben_counters *cnt)
 {
@@ -509,6 +540,7 @@ static int gm_core(const gm_variant *v, const double *X, const double *y, int N,
     s->v = *v;
     s->N = N; s->K = K; s->X = X; s->y = y; s->lambda = lambda; s->alpha = alpha;
     s->cap = cap;
+    s->cap_ref = cap_ref;
     s->scale = (double *)calloc(K, sizeof(double));
     memcpy(s->scale, scale_in, sizeof(double) * K);
     s->t = (double *)calloc(N, sizeof(double));
@@ -581,8 +613,8 @@ int eben_gm_fit(const double *X, const double *y, int N, int K, double lambda, d
                 eben_counters *cnt)
 {
     const gm_variant v = {0, 0.9, 0.001, 1e-3, 1e2, 1e-10};
-    int cap = (int)(1e7 / K);                      /* basisMax, :68-69 */
-    if (cap > K) cap = K;
+    int cap, cap_ref;
+    capacities((int)(1e7 / K), K, N, &cap_ref, &cap);   /* basisMax = min(K, 1e7/K), :68-69 */
     double *scale = (double *)calloc(K, sizeof(double));
     for (int i = 0; i < K; i++) {
         Beta[i] = i + 1; Beta[K + i] = i + 1; Beta[2 * (size_t)K + i] = 0; Beta[3 * (size_t)K + i] = 0;
@@ -593,7 +625,7 @@ int eben_gm_fit(const double *X, const double *y, int N, int K, double lambda, d
     int M = 0;
     int *used = (int *)calloc(cap + 1, sizeof(int));
     double *w = (double *)calloc(cap + 1, sizeof(double)), *vr = (double *)calloc(cap + 1, sizeof(double));
-    int rc = gm_core(&v, X, y, N, K, cap, scale, lambda, alpha, &M, used, w, vr, wald, intercept, residual, cnt);
+    int rc = gm_core(&v, X, y, N, K, cap, cap_ref, scale, lambda, alpha, &M, used, w, vr, wald, intercept, residual, cnt);
     for (int i = 0; i < M; i++) { Beta[2 * (size_t)K + used[i]] = w[i]; Beta[3 * (size_t)K + used[i]] = vr[i]; }
     free(scale); free(used); free(w); free(vr);
     return rc;
@@ -607,9 +639,8 @@ int eben_gf_fit(const double *X, const double *y, int N, int K, double lambda, d
 {
     const gm_variant v = {1, 0.99, 0.01, 0.1, 1e3, 0.0};
     const size_t MF = (size_t)K * (K + 1) / 2;
-    int cap;                                       /* Full2.c:67-80 */
-    if (N > K) cap = 2 * K; else if (N < 200) cap = 4 * K; else cap = K;
-    if ((size_t)cap > MF) cap = (int)MF;
+    int cap, cap_ref;                              /* Full2.c:67-80 */
+    capacities(N > K ? 2 * K : (N < 200 ? 4 * K : K), (long)MF, N, &cap_ref, &cap);
     double *Z = (double *)malloc(sizeof(double) * (size_t)N * MF);
     double *scale = (double *)calloc(MF, sizeof(double));
     if (!Z || !scale) { free(Z); free(scale); return -2; }
@@ -636,7 +667,7 @@ int eben_gf_fit(const double *X, const double *y, int N, int K, double lambda, d
     int M = 0;
     int *used = (int *)calloc(cap + 1, sizeof(int));
     double *w = (double *)calloc(cap + 1, sizeof(double)), *vr = (double *)calloc(cap + 1, sizeof(double));
-    int rc = gm_core(&v, Z, y, N, (int)MF, cap, scale, lambda, alpha, &M, used, w, vr, wald, intercept, residual, cnt);
+    int rc = gm_core(&v, Z, y, N, (int)MF, cap, cap_ref, scale, lambda, alpha, &M, used, w, vr, wald, intercept, residual, cnt);
     for (int i = 0; i < M; i++) {
         Beta[2 * MF + used[i]] = w[i]; Beta[3 * MF + used[i]] = vr[i]; Beta[4 * MF + used[i]] = used[i] + 1;   /* :232-238 */
     }

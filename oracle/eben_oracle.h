@@ -30,6 +30,11 @@ typedef struct {
                              bit2 stale-index delete path (reference UB) taken      */
 } eben_counters;
 
+/* Capacity policy of the Gaussian fits (eben_gm.c): default (0, 0) = the reference's basisMax stops a fit;
+ * (1, r) = flag (status bit 0) and continue up to max(basisMax, min(N, 1024)) like the HIP build, with
+ * basisMax lowered to r when r > 0.  Process-wide; set before fitting. */
+void eben_set_capacity_policy(int continue_past_basismax, int ref_cap_override);
+
 /* Gaussian, main effects.  Follows EBEN_orig/src/elasticNetLinearNeMainEff.c:55-242.
  * X is N x K column-major, Beta is K x 4 column-major (loc1, loc2, beta, var). */
 int eben_gm_fit(const double *X, const double *y, int N, int K, double lambda, double alpha,

@@ -7,9 +7,9 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PAREBEN_LIB=<path> loads another build of the same library (A/B timing of kernel variants, diagnostic builds)
 LIB_PATH = os.environ.get("PAREBEN_LIB") or os.path.join(_HERE, "lib", "libpareben_hip.so")
-NCOUNTERS = 12
+NCOUNTERS = 13
 COUNTER_NAMES = ("n_outer", "n_inner", "n_add", "n_del", "n_reest", "n_fullstat", "sum_m_action",
-                 "sum_m_full", "sum_m2_full", "m_final", "m_max", "status")
+                 "sum_m_full", "sum_m2_full", "m_final", "m_max", "status", "mfma_tiles")
 ST_OVERFLOW, ST_CHOLESKY, ST_STALE, ST_ABORT = 1, 2, 4, 8
 
 _lib = None
@@ -82,7 +82,7 @@ class Context:
                                   0 if prior == "gaussian" else 1, 1 if epis else 0, int(max_active)), "pareben_ctx_create")
 
     def run(self, alpha, lam, want_counters=True):
-        """-> (fold_err [n_cells, n_folds], status [n_cells, n_folds], counters [n_cells, n_folds, 12] | None)"""
+        """-> (fold_err [n_cells, n_folds], status [n_cells, n_folds], counters [n_cells, n_folds, 13] | None)"""
         L = load()
         alpha = np.ascontiguousarray(alpha, dtype=np.float64).reshape(-1)
         lam = np.ascontiguousarray(lam, dtype=np.float64).reshape(-1)
@@ -107,9 +107,10 @@ class Context:
         return {"prep_ms": float(ms[0]), "fit_ms": float(ms[1]), "total_ms": float(ms[2])}
 
     def launch_info(self):
-        info = np.zeros(4, dtype=np.int64)
+        info = np.zeros(5, dtype=np.int64)
         _chk(load().pareben_ctx_launch_info(self._h, _lp(info)), "pareben_ctx_launch_info")
-        return {"workgroups": int(info[0]), "threads": int(info[1]), "capacity": int(info[2]), "ws_kib": int(info[3])}
+        return {"workgroups": int(info[0]), "threads": int(info[1]), "capacity": int(info[2]), "ws_kib": int(info[3]),
+                "reference_capacity": int(info[4])}
 
     def close(self):
         if self._h:

@@ -124,6 +124,7 @@ template <class T> DEV T *uni_ptr(T *p)
 #define FS_APRE 1           // tiles by which the LDS reads of the A operands run ahead of the matrix ops
 #endif
 #define FS_PPW (FS_TPP / FS_NWAVES)   // Sigma panels each wave stages per step
+#define FS_MAX_M 2048      // largest active set the pass is laid out for (LDS: row offsets + mu); the host bounds every capacity by it
 static_assert(FS_TPP % FS_NWAVES == 0 && 16 % FS_NB == 0, "full-stat tiling");
 
 // The full-stat pass is ONE software pipeline over all (feature tile, pass, k-block) steps of a call:
@@ -163,8 +164,9 @@ DEV void fs_advance(FsCur &c, int n_pass, int nJ, int first)
 // consecutive features of one Gram row per 16 lanes, i.e. whole 128-byte lines -- and a wave needs only its
 // own column blocks, so the Gram block is not shared through LDS at all: each wave loads its operands for
 // step g+1 straight into a register ring during step g (loff[p] = byte offset of Gram row p of the active
-// set).  Rows >= M are zeroed when they are used, and the Sigma panels are staged with exact zeros outside
-// the active block, so nothing the workspace holds beyond it (stale values of earlier fits) reaches a result.
+// set).  Rows >= M are zeroed when they are used; the Sigma entries of the ragged 16-block beyond the active
+// set are multiplied by those zeros, so they must be finite: gm_fullstat clears that band before every pass
+// (whatever an earlier fit of this workgroup left there -- possibly NaN -- never reaches a result).
 // Sigma is symmetric: row tile J only visits k-blocks h <= J and counts h < J twice (the panel is
 // doubled when it is staged; doubling is exact).
 // When h == J the k-block on the diagonal IS tile J's own rows, and the rows a lane holds as B operand
@@ -264,14 +266,10 @@ DEV void fs_step(gptr_cc Sig, gptr_cc G, lptr_cull loff, lptr_d lmu, lptr_d acur
     for (int pi = 0; pi < FS_PPW; pi++) {
         const int t = wave + pi * FS_NWAVES, J = fs_pass_begin(c1.pass, first) + t;
         const double w = c1.h < J ? 2.0 : 1.0;
-        const bool row_in = J * 16 + l15 < M;
 #pragma unroll
         for (int s = 0; s < 4; s++) {
             double v = pa[NX][pi][s] * w;
             asm volatile("" : "+v"(v));                        // consume the load on every path (see above)
-            // entries of the ragged 16-block beyond the active set are staged as exact zeros whatever the
-            // workspace holds there (a previous fit of this workgroup may have left non-finite values)
-            if (!(row_in && c1.h * 16 + 4 * s + l4 < M)) v = 0.0;
             if (J < fs_pass_end(c1.pass, first) && c1.h <= J) anxt[(t * 4 + s) * 64 + lane] = v;
         }
     }
@@ -312,9 +310,9 @@ DEVNI void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W,
     const gptr_cd gbt = as_global(uni_ptr(W.bt));
     double *pool = uni_ptr(B.pool);
     const lptr_d la = as_lds(pool);                                         // 2 x FS_TPP x 256 staged Sigma panels
-    unsigned long long *loff_w = (unsigned long long *)(pool + 2 * FS_TPP * 256);          // Gram row byte offsets, M <= 1024
+    unsigned long long *loff_w = (unsigned long long *)(pool + 2 * FS_TPP * 256);          // Gram row byte offsets, M <= FS_MAX_M
     const lptr_cull loff = (lptr_cull)loff_w;
-    const lptr_d lmu = as_lds(pool + 2 * FS_TPP * 256 + 1024);              // mu, zero-padded to a k-block
+    const lptr_d lmu = as_lds(pool + 2 * FS_TPP * 256 + FS_MAX_M);          // mu, zero-padded to a k-block
     K = uni(K); M = uni(M);
     const int ld = uni(W.ld);
     const int nJ = (M + 15) >> 4;
@@ -368,7 +366,7 @@ DEVNI void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W,
             for (int s = 0; s < 4; s++) {
                 const double v0 = *(gptr_cd)(Sig + (o0 + s * st0));
                 pa[1][pi][s] = *(gptr_cd)(Sig + (o1 + s * st1));
-                if (on0) la[(t * 4 + s) * 64 + lane] = (t * 16 + l15 < M && 4 * s + l4 < M) ? v0 * (0 < t ? 2.0 : 1.0) : 0.0;
+                if (on0) la[(t * 4 + s) * 64 + lane] = v0 * (0 < t ? 2.0 : 1.0);
             }
         }
     }
@@ -543,6 +541,16 @@ DEV void gm_fullstat(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmS
         W.mu[i] = a * beta;
         if (i >= 1) W.gam[i] = 1 - W.Sig[(size_t)i * ld + i] * W.A[i];
     }
+#ifndef PAREBEN_HOST_EMUL
+    {   // the band between the active block and the next multiple of 16 (see fs_step): exact zeros for the matrix-core pass
+        const int Mp = ((M + 15) >> 4) << 4, pad = Mp - M;
+        for (int e = B.tid; e < Mp * pad; e += B.nthr) {
+            const int j = e / pad, i = M + e - j * pad;
+            W.Sig[(size_t)j * ld + i] = 0.0;
+            W.Sig[(size_t)i * ld + j] = 0.0;
+        }
+    }
+#endif
     blk_sync(B);
     {
         PH_BEGIN();
@@ -557,6 +565,10 @@ DEV void gm_fullstat(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmS
     }
     gm_refresh_out(B, W, K);
     CNT(c.n_fullstat++; c.sum_m_full += M; c.sum_m2_full += (int64_t)M * M);
+#ifndef PAREBEN_HOST_EMUL
+    // matrix-core work of the pass: per 16-feature block the triangle of (row tile J, k-block h <= J) tile products
+    CNT(const int64_t nJ = (M + 15) >> 4; c.mfma_tiles += (int64_t)((K + FS_FT - 1) / FS_FT) * (FS_FT / 16) * (nJ * (nJ + 1) / 2));
+#endif
 }
 
 // Per-feature marginal-likelihood change and action, MainEff.c:1372-1582.  Returns the arg-max
@@ -954,17 +966,17 @@ DEVNI int gm_row(const Blk &B, const FoldDev &F, const GmWork &W, int K, int u)
     const int N = F.N;
     double *row = const_cast<double *>(F.G) + (size_t)my * K;
     const double *xu = F.X + (size_t)u * N;
-    const double ru = F.rscale[u];
+    const double su = F.scale[u];                               // PHI = x_u / |x_u| as the reference forms it (:1608-1617)
     const bool in_lds = N <= B.pool_n;
     if (in_lds) {
-        PAR(h, N) B.pool[h] = xu[h] * ru;
+        PAR(h, N) B.pool[h] = xu[h] / su;
         blk_sync(B);
     }
 #ifdef PAREBEN_HOST_EMUL
     for (int i = B.wave; i < K; i += B.nwave) {
         const double *xi = F.X + (size_t)i * N;
         double a = 0;
-        for (int h = B.lane; h < N; h += BLK_LANES) a += xi[h] * (xu[h] * ru);
+        for (int h = B.lane; h < N; h += BLK_LANES) a += xi[h] * (xu[h] / su);
         if (B.lane == 0) row[i] = a / F.scale[i];
     }
 #else
@@ -976,7 +988,7 @@ DEVNI int gm_row(const Blk &B, const FoldDev &F, const GmWork &W, int K, int u)
             const double *xi = F.X + (size_t)(i0 + c < K ? i0 + c : K - 1) * N;
             double t = 0;
             if (in_lds) for (int h = B.lane; h < N; h += BLK_LANES) t += xi[h] * B.pool[h];
-            else for (int h = B.lane; h < N; h += BLK_LANES) t += xi[h] * (xu[h] * ru);
+            else for (int h = B.lane; h < N; h += BLK_LANES) t += xi[h] * (xu[h] / su);
             a[c] = t;
         }
         wave_sum8(a, B.lane);
@@ -1160,8 +1172,8 @@ DEVNI void gm_rows_prefetch(const Blk &B, const FoldDev &F, int K, const int *nu
     if (C == 0) return;
     for (int c = 0; c < C; c++) {
         const double *xu = F.X + (size_t)lfeat[c] * N;
-        const double ru = F.rscale[lfeat[c]];
-        PAR(h, N) B.pool[c * N + h] = xu[h] * ru;
+        const double su = F.scale[lfeat[c]];
+        PAR(h, N) B.pool[c * N + h] = xu[h] / su;
     }
     blk_sync(B);
     double *Gw = const_cast<double *>(F.G);
@@ -1699,6 +1711,10 @@ DEVNI int gm_final_update(const Blk &B, const FoldDev &F, const GmWork &W, int K
     PAR(l, M) W.v1[l] = W.bt[W.used[l]];
     blk_sync(B);
     { PH_BEGIN(); const int bad = gm_spd_inverse(B, W, M, S.ph); PH_END(PH_INVERSE); if (bad) return 1; }
+#ifndef PAREBEN_HOST_EMUL
+    // blocked inverse: per 16-pivot step one panel product per row tile + the triangle of trailing tiles
+    if (M > 16) CNT(const int64_t nT = (M + 15) >> 4; c.mfma_tiles += nT * (nT + (nT - 1) * nT / 2));
+#endif
     PH_BEGIN();
 #ifdef PAREBEN_HOST_EMUL
     PAR(i, M) {
@@ -1877,6 +1893,7 @@ DEV int gm_inner(const Blk &B, const FoldDev &F, const GmWork &W, int K, double 
                         if (!ok) { S.status |= ST_OVERFLOW | ST_ABORT; return 1; }
                         CNT(c.n_add += T; c.sum_m_action += (int64_t)T * S.M + (int64_t)T * (T - 1) / 2);
                         gm_add_batch(B, F, W, K, S, W.todo + u, T);
+                        if (S.M > W.cap_flag) S.status |= ST_OVERFLOW;   // past the reference's basisMax (MainEff.c:605-611): flagged, not stopped
                         u += T - 1;
                         nu = W.todo[u];
                         sel = ACT_ADD;
@@ -1914,6 +1931,7 @@ DEV int gm_inner(const Blk &B, const FoldDev &F, const GmWork &W, int K, double 
                     if (rid < 0) { S.status |= ST_OVERFLOW | ST_ABORT; return 1; }
                     CNT(c.n_add++; c.sum_m_action += S.M);
                     gm_add(B, F, W, K, S, nu, rid, newA);
+                    if (S.M > W.cap_flag) S.status |= ST_OVERFLOW;
                     upd = true;
                 } else if (sel == ACT_DEL) {
                     CNT(c.n_del++; c.sum_m_action += S.M);

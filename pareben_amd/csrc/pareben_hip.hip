@@ -140,49 +140,49 @@ __global__ void ystats_kernel(const double *__restrict__ y, int N, double *__res
     if (threadIdx.x == 0) { out[0] = m; out[1] = v / (N - 1); }
 }
 
-// Normalised Gram matrix of one fold: G[u*K + i] = D[u][i] * rscale[u] / scale[i] with D = X'X, i.e. the
-// reference's BASIS_PHI row of basis u (x_i . (x_u/|x_u|) / |x_i|, elasticNetLinearNeMainEff.c:1171-1177,
-// :1608-1630) for every u at once.  D is symmetric, so only the blocks on and below the diagonal are
-// computed (half of the 2 N K^2 flops) and each is stored twice with its own scaling.
+// Normalised Gram matrix of one fold: G[u*K + i] = ( sum_h X[h,i] * (X[h,u] / scale[u]) ) / scale[i], i.e. the
+// reference's BASIS_PHI row of basis u (PHI = x_u/|x_u| dotted with every column, then divided by that
+// column's norm: elasticNetLinearNeMainEff.c:1171-1177, :1608-1630) for every u at once.
+//   * Same operations in the same order as the reference's sequential dot product: the u-operand is divided by
+//     its norm when it is staged, and a 16 x 16 accumulator tile of v_mfma_f64_16x16x4_f64 is ONE fma chain
+//     over the samples h in ascending order (the matrix op rounds like four chained fmas,
+//     tools/ubench/mfma_f64_order.hip).  For integer-coded designs (genotypes: -1/0/1) every product is exact,
+//     so G equals the reference's values bit for bit -- which is what keeps the long add/delete trajectories of
+//     the real-R table on the reference's path ("Parity on chaotic fits").  The price: x_u/|x_u| on
+//     one side only makes the two triangles round differently, so all K^2 entries are computed (a
+//     symmetric-half version was 2x faster and lost that parity; profiles/r02).
 //   * FP64 matrix cores: a 128 x 128 block per 256-thread workgroup, 64 x 64 per wave = 4 x 4 accumulator
-//     tiles of v_mfma_f64_16x16x4_f64 (A rows <-> u, B columns <-> i, k <-> sample h).  A tile's sum is one
-//     fma chain over h ascending (the matrix op rounds like four chained fmas, tools/ubench/mfma_f64_order.hip),
-//     so D[u][i] == D[i][u] bit for bit and the values do not depend on the tiling.
+//     tiles (A rows <-> u, B columns <-> i, k <-> sample h).
 //   * Operands: 16-sample slabs of the two 128-column panels, loaded with 16 lanes along h (columns are
 //     contiguous in h: whole 128-byte lines), staged in LDS as [column][h] with pitch 17 and double
 //     buffered: the loads of slab s+1 are in flight while slab s feeds the matrix cores; one barrier per slab.
 //     Per slab and workgroup: 32 KB loaded for 0.5 MFLOP -> far from any memory bound once the panels of
 //     concurrently running blocks come out of L2.
 //   * XCD-aware block order: workgroup b runs on XCD b % 8, which is given a contiguous range of the
-//     row-major lower-triangle block list, so the 32 CUs of an XCD work on consecutive blocks of one block
-//     row at any time (one shared u-panel, neighbouring i-panels) and their panels meet in that XCD's L2.
-//   * Mirror store: each 16 x 16 tile is transposed through a wave-private LDS patch so that both copies
-//     leave as 128-byte row segments.
+//     row-major block list, so the 32 CUs of an XCD work on consecutive blocks of one block row at any time
+//     (one shared u-panel, neighbouring i-panels) and their panels meet in that XCD's L2.
 #define GB 128
 #define GS 16
 #define GP 17
 typedef double gd4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256, 2) void gram_kernel(const double *__restrict__ X, int N, int K,
                                                       const double *__restrict__ scale,
-                                                      const double *__restrict__ rscale,
                                                       double *__restrict__ G, int nb, int n_blocks)
 {
     __shared__ double sm[2][2][GB * GP];
     const int per = (n_blocks + 7) / 8;
     const int lin = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
     if (lin >= n_blocks) return;                                  // uniform per workgroup, before any barrier
-    (void)nb;
-    int bu = (int)((sqrt(8.0 * (double)lin + 1.0) - 1.0) * 0.5);
-    while ((long long)(bu + 1) * (bu + 2) / 2 <= lin) bu++;
-    while ((long long)bu * (bu + 1) / 2 > lin) bu--;
-    const int bi = lin - (int)((long long)bu * (bu + 1) / 2);     // bi <= bu
-    const bool diag = bu == bi;
+    const int bu = lin / nb, bi = lin - bu * nb;
     const int u0 = bu * GB, i0 = bi * GB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     const int wu = wave >> 1, wi = wave & 1;
     // staging: thread -> sample h = tid & 15 of columns (tid >> 4) + 16 q
     const int sh = tid & 15, sc = tid >> 4;
+    double su[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) { const int cu = u0 + sc + 16 * q; su[q] = cu < K ? scale[cu] : 1.0; }
     gd4 acc[4][4];
 #pragma unroll
     for (int a = 0; a < 4; a++)
@@ -195,14 +195,14 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const double *__restrict__
         for (int q = 0; q < 8; q++) {
             const int cu = u0 + sc + 16 * q, ci = i0 + sc + 16 * q;
             ra[q] = (hh < N && cu < K) ? X[(size_t)cu * N + hh] : 0.0;
-            rb[q] = (!diag && hh < N && ci < K) ? X[(size_t)ci * N + hh] : 0.0;
+            rb[q] = (hh < N && ci < K) ? X[(size_t)ci * N + hh] : 0.0;
         }
     };
     auto stash = [&](int buf) {
 #pragma unroll
         for (int q = 0; q < 8; q++) {
-            sm[buf][0][(sc + 16 * q) * GP + sh] = ra[q];
-            if (!diag) sm[buf][1][(sc + 16 * q) * GP + sh] = rb[q];
+            sm[buf][0][(sc + 16 * q) * GP + sh] = ra[q] / su[q];   // PHI = x_u / |x_u|  (:1608-1617)
+            sm[buf][1][(sc + 16 * q) * GP + sh] = rb[q];
         }
     };
     const int n_slab = (N + GS - 1) / GS;
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const double *__restrict__
         const int buf = s & 1;
         if (s + 1 < n_slab) fetch((s + 1) * GS);
         const double *pa = &sm[buf][0][(wu * 64 + l15) * GP + l4];
-        const double *pb = &sm[buf][diag ? 0 : 1][(wi * 64 + l15) * GP + l4];
+        const double *pb = &sm[buf][1][(wi * 64 + l15) * GP + l4];
 #pragma unroll
         for (int ks = 0; ks < GS / 4; ks++) {
             double av[4], bv[4];
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const double *__restrict__
         if (s + 1 < n_slab) stash(buf ^ 1);
         __syncthreads();
     }
-    // direct copy: rows u, 16 consecutive i per 16 lanes
+    // rows u, 16 consecutive i per 16 lanes: 128-byte row segments
     double sci[4];
 #pragma unroll
     for (int b = 0; b < 4; b++) {
@@ -240,41 +240,12 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const double *__restrict__
         for (int r = 0; r < 4; r++) {
             const int u = u0 + wu * 64 + a * 16 + l4 + 4 * r;
             if (u >= K) continue;
-            const double rs = rscale[u];
 #pragma unroll
             for (int b = 0; b < 4; b++) {
                 const int i = i0 + wi * 64 + b * 16 + l15;
-                if (i < K) G[(size_t)u * K + i] = acc[a][b][r] * rs / sci[b];
+                if (i < K) G[(size_t)u * K + i] = acc[a][b][r] / sci[b];
             }
         }
-    if (diag) return;                                             // the full block was computed: both triangles are stored
-    // mirrored copy G[i][u] = D[u][i] * rscale[i] / scale[u]: tile transposed through a wave-private patch
-    double *patch = &sm[0][0][0] + wave * (16 * GP);
-#pragma unroll
-    for (int a = 0; a < 4; a++) {
-        const int u = u0 + wu * 64 + a * 16 + l15;               // after the transpose a lane holds row u = l15 of the tile
-        const double scu = u < K ? scale[u] : 1.0;
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) patch[(l4 + 4 * r) * GP + l15] = acc[a][b][r];      // [row u][col i]
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_s_waitcnt(0xC07F);
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int ic = l4 + 4 * r;                         // column of the tile = feature i
-                const int i = i0 + wi * 64 + b * 16 + ic;
-                const double d = patch[l15 * GP + ic];             // D[u = l15][i = ic]
-                if (u < K && i < K) G[(size_t)i * K + u] = d * rscale[i] / scu;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_s_waitcnt(0xC07F);
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -318,7 +289,7 @@ __device__ inline GmWork ws_carve(char *base, int K, int cap, size_t offK, size_
     W.pfree = W.rowid + c1;
     W.priv_base = 0; W.priv_rows = 0;
     W.e = nullptr;
-    W.cap = cap; W.ld = ldp;
+    W.cap = cap; W.ld = ldp; W.cap_flag = cap;
     return W;
 }
 
@@ -377,7 +348,7 @@ struct CvParams {
     long long *phase;                 // [n_units x PH_N] diagnostic ticks, may be null
     char *ws;
     size_t ws_stride, offK, offSig, offM;
-    int K, cap, n_folds, n_units;
+    int K, cap, cap_flag, n_folds, n_units;
     int priv_base0, priv_rows;         // lazy Gram mode: private rows of workgroup b start at priv_base0 + b * priv_rows
     FsJob *jobs;                       // shared phases (gm_fit.h); null = off
     int *active;
@@ -389,7 +360,7 @@ struct CvParams {
 // LDS carve of one fit workgroup (dynamic shared memory): a phase-local pool (full-stat Gram
 // k-blocks and Sigma panels / inverse panels / action vectors) and the small reduction scratch.
 #ifndef LDS_POOL_DOUBLES
-#define LDS_POOL_DOUBLES 16384
+#define LDS_POOL_DOUBLES 19456    // 152 KB of the CU's 160 KB: the blocked inverse keeps its M x 16 panel (pitch 18) in it up to M = 1040
 #endif
 #define LDS_FIT_BYTES ((LDS_POOL_DOUBLES + 2 * BLK_MAX_WAVES) * 8 + 4 * BLK_MAX_WAVES * 4)
 extern __shared__ double lds_dyn[];
@@ -411,7 +382,7 @@ __device__ inline void store_counters(long long *dst, const FitCounters &c)
 {
     dst[0] = c.n_outer; dst[1] = c.n_inner; dst[2] = c.n_add; dst[3] = c.n_del; dst[4] = c.n_reest;
     dst[5] = c.n_fullstat; dst[6] = c.sum_m_action; dst[7] = c.sum_m_full; dst[8] = c.sum_m2_full;
-    dst[9] = c.m_final; dst[10] = c.m_max; dst[11] = c.status;
+    dst[9] = c.m_final; dst[10] = c.m_max; dst[11] = c.status; dst[12] = c.mfma_tiles;
 }
 
 // A workgroup that found the work queue empty helps the fits still running: it scans the job board (64
@@ -501,6 +472,7 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_EU) void gm_cv_kernel(Cv
     GmWork W = ws_carve(P.ws + (size_t)blockIdx.x * P.ws_stride, P.K, P.cap, P.offK, P.offSig, P.offM);
     W.priv_rows = P.priv_rows;
     W.priv_base = P.priv_base0 + (int)blockIdx.x * P.priv_rows;
+    W.cap_flag = P.cap_flag;
     FsShare sh;
     sh.jobs = P.jobs; sh.active = P.active; sh.queue = P.queue; sh.n_units = P.n_units; sh.n_blocks = gridDim.x;
     sh.self = blockIdx.x; sh.ws = P.ws; sh.ws_stride = P.ws_stride; sh.offK = P.offK; sh.offSig = P.offSig; sh.offM = P.offM;
@@ -608,7 +580,7 @@ struct FitParams {
     long long *counters;
     char *ws;
     size_t offK, offSig, offM;
-    int K, cap;
+    int K, cap, cap_flag;
     int p;               // design columns (K = p without epistasis)
     GmVariant v;
 };
@@ -621,7 +593,8 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_EU) void gm_fit_kernel(F
     __shared__ FitCounters s_cnt;
     __shared__ long long s_ph[PH_N];
     const Blk B = make_blk();
-    const GmWork W = ws_carve(P.ws, P.K, P.cap, P.offK, P.offSig, P.offM);
+    GmWork W = ws_carve(P.ws, P.K, P.cap, P.offK, P.offSig, P.offM);
+    W.cap_flag = P.cap_flag;
     const int K = P.K, p = P.p;
     const int ncol = P.v.epis ? 5 : 4;
     PAR(i, p) { P.Beta[i] = i + 1; P.Beta[(size_t)K + i] = i + 1; }
@@ -723,7 +696,9 @@ struct FoldHost {
 };
 
 struct pareben_ctx {
-    int device = 0, n = 0, p = 0, n_folds = 0, prior = 0, epis = 0, cap = 0;
+    int device = 0, n = 0, p = 0, n_folds = 0, prior = 0, epis = 0;
+    int cap = 0;            // active-set capacity of the fit workspaces
+    int cap_ref = 0;        // the reference's basisMax (<= cap): fits whose active set grows past it are flagged
     int kfull = 0;          // columns the fit sees: p, or p(p+1)/2 with epistasis
     GmVariant variant{};
     double *d_basis = nullptr, *d_y = nullptr;
@@ -735,7 +710,7 @@ struct pareben_ctx {
     WsLayout L{};
     BmLayout BL{};
     double last_ms[3] = {0, 0, 0};
-    int64_t launch_info[4] = {0, 0, 0, 0};
+    int64_t launch_info[5] = {0, 0, 0, 0, 0};
     int n_cu = 0;
     // on-demand Gram rows (K x K per fold does not fit): [lazy_hdr ints of pool counters][n_folds x K slots]
     int lazy = 0, pool_rows = 0, priv_rows = 0, max_blocks = 0, lazy_hdr = 0;
@@ -743,14 +718,29 @@ struct pareben_ctx {
     double *d_rows = nullptr;   // lazy mode: n_folds pools of pool_rows rows, then max_blocks x priv_rows private rows
 };
 
-static int default_cap(int K, int max_active)
+// Active-set capacities.  The reference sizes its per-fit arrays for basisMax = min(K, 1e7/K) columns
+// (elasticNetLinearNeMainEff.c:68-69; elasticNetLinearNeFull2.c:67-80 for epistasis) and, when a fit grows
+// past that, prints "out of Memory" and keeps writing (:605-611) -- undefined behaviour, at K = 50 000 already
+// from 200 columns on.  Policy here: `cap_ref` is that number and only FLAGS a fit (PAREBEN_ST_OVERFLOW);
+// the fit goes on in a workspace of `cap` >= cap_ref columns, cap = max(cap_ref, min(N_train, 1024)) bounded
+// by K and by what the matrix-core passes are laid out for, and is stopped (ST_OVERFLOW | ST_ABORT, score
+// NaN) only there.  An active set larger than the number of training rows is not a model the algorithm
+// keeps (delete priority from M >= N on), so min(N_train, .) costs nothing; 1024 bounds the workspace
+// (3 x cap^2 doubles per resident fit).  max_active > 0 (ctx_create) lowers both; PAREBEN_REF_CAP=<n> lowers
+// cap_ref alone (tests: the flag-and-continue path at sizes the oracle can follow).
+static void capacities(int K, int ref_rule, int n_train_max, int max_active, int *cap_ref_out, int *cap_out)
 {
-    long cap = (long)(1e7 / K);
+    long ref = ref_rule;
+    if (ref > K) ref = K;
+    long cap = std::max<long>(ref, std::min(n_train_max, 1024));
     if (cap > K) cap = K;
-    if (max_active > 0) { if (cap > max_active) cap = max_active; }
-    else if (cap > 2048) cap = 2048;
+    if (cap > FS_MAX_M) cap = FS_MAX_M;
+    if (max_active > 0 && cap > max_active) cap = max_active;
     if (cap < 2) cap = 2;
-    return (int)cap;
+    if (const char *e = getenv("PAREBEN_REF_CAP")) { const long v = atol(e); if (v > 0 && v < ref) ref = v; }
+    if (ref > cap) ref = cap;
+    if (ref < 1) ref = 1;
+    *cap_ref_out = (int)ref; *cap_out = (int)cap;
 }
 
 template <class T> static hipError_t dmalloc(T **p, size_t count)
@@ -788,19 +778,18 @@ static int ctx_create_impl(pareben_ctx **out, int device, const double *basis, i
     c->device = device; c->n = n; c->p = p; c->n_folds = n_folds; c->prior = prior; c->epis = epis;
     c->kfull = epis ? (int)((long long)p * (p + 1) / 2) : p;
     if (epis && (long long)p * (p + 1) / 2 > 2000000000LL) { delete c; return fail(PAREBEN_EINVAL, "too many pairwise columns"); }
+    int n_train_max = 2;
+    for (auto &tr : rows_tr) n_train_max = std::max(n_train_max, (int)tr.size());
     if (!epis) {
-        c->cap = default_cap(p, max_active);
+        capacities(c->kfull, (int)std::min<double>(1e7 / p, 2e9), n_train_max, max_active, &c->cap_ref, &c->cap);
         c->variant = GmVariant{0, 0.9, 0.001, 1e-3, 1e2, 1e-10};
-    } else {                                       // basisMax of elasticNetLinearNeFull2.c:67-80, bounded
-        int cap = 0;
+    } else {                                       // basisMax of elasticNetLinearNeFull2.c:67-80
+        int ref = 0;
         for (auto &tr : rows_tr) {
             const int N = (int)tr.size();
-            const int c1 = N > p ? 2 * p : (N < 200 ? 4 * p : p);
-            cap = std::max(cap, c1);
+            ref = std::max(ref, N > p ? 2 * p : (N < 200 ? 4 * p : p));
         }
-        if (cap > c->kfull) cap = c->kfull;
-        if (max_active > 0) cap = std::min(cap, max_active); else cap = std::min(cap, 2048);
-        c->cap = std::max(cap, 2);
+        capacities(c->kfull, ref, n_train_max, max_active, &c->cap_ref, &c->cap);
         c->variant = GmVariant{1, 0.99, 0.01, 0.1, 1e3, 0.0};
     }
     const size_t KF = (size_t)c->kfull;
@@ -911,11 +900,11 @@ static int prepare_folds(pareben_ctx *c)
         if (H.nte) hipLaunchKernelGGL(gather_kernel, dim3((H.nte + 255) / 256), dim3(256), 0, c->stream, c->d_y, H.d_te, H.nte, H.yte);
         hipLaunchKernelGGL(colstats_kernel, dim3(kf), dim3(256), 0, c->stream, H.X, H.y, H.N, H.scale, H.rscale, H.bt0, H.cs);
         hipLaunchKernelGGL(ystats_kernel, dim3(1), dim3(256), 0, c->stream, H.y, H.N, H.ystat);
-        if (H.G) {                                  // lower-triangle blocks, dealt to the XCDs in contiguous ranges
+        if (H.G) {                                  // 128 x 128 blocks, dealt to the XCDs in contiguous ranges of the row-major list
             const int nb = (kf + GB - 1) / GB;
-            const long long nbl = (long long)nb * (nb + 1) / 2;
+            const long long nbl = (long long)nb * nb;
             const int per = (int)((nbl + 7) / 8);
-            hipLaunchKernelGGL(gram_kernel, dim3(per * 8), dim3(256), 0, c->stream, H.X, H.N, kf, H.scale, H.rscale, H.G, nb, (int)nbl);
+            hipLaunchKernelGGL(gram_kernel, dim3(per * 8), dim3(256), 0, c->stream, H.X, H.N, kf, H.scale, H.G, nb, (int)nbl);
         }
         // ymean / varY live inside the FoldDev record: copy the two doubles device-to-device
         HIPCHK(hipMemcpyAsync((char *)(c->d_folds + f) + offsetof(FoldDev, ymean), H.ystat, 2 * sizeof(double),
@@ -1037,7 +1026,7 @@ extern "C" int pareben_ctx_run(pareben_ctx *c, int n_cells, const double *alpha,
     P.folds = c->d_folds; P.alpha = d_alpha; P.lambda = d_lambda; P.order = d_order; P.queue = d_queue;
     P.fold_err = d_err; P.status = d_status; P.counters = d_cnt; P.phase = d_phase; P.ws = c->d_ws;
     P.ws_stride = c->L.bytes; P.offK = c->L.offK; P.offSig = c->L.offSig; P.offM = c->L.offM;
-    P.K = c->kfull; P.cap = c->cap; P.n_folds = nF; P.n_units = n_units; P.v = c->variant;
+    P.K = c->kfull; P.cap = c->cap; P.cap_flag = c->cap_ref; P.n_folds = nF; P.n_units = n_units; P.v = c->variant;
     P.priv_rows = c->priv_rows; P.priv_base0 = nF * c->pool_rows;
     P.jobs = d_jobs; P.active = d_active;
     // with only a handful of fits per workgroup the longest fits decide the step time: share from the start
@@ -1073,8 +1062,9 @@ extern "C" int pareben_ctx_run(pareben_ctx *c, int n_cells, const double *alpha,
     CK(hipEventElapsedTime(&b, c->ev[1], c->ev[2]));
     CK(hipEventElapsedTime(&t, c->ev[0], c->ev[3]));
     c->last_ms[0] = a; c->last_ms[1] = b; c->last_ms[2] = t;
-    c->launch_info[0] = blocks; c->launch_info[1] = FIT_THREADS; c->launch_info[2] = c->cap;
+    c->launch_info[0] = blocks; c->launch_info[1] = FIT_THREADS;
     c->launch_info[2] = binom ? c->BL.cap : c->cap;
+    c->launch_info[4] = binom ? c->BL.cap : c->cap_ref;
     c->launch_info[3] = (int64_t)((binom ? c->BL.bytes : c->L.bytes) >> 10);
 #undef CK
     cleanup();
@@ -1105,10 +1095,10 @@ extern "C" int pareben_ctx_last_timing(pareben_ctx *c, double ms[3])
     return PAREBEN_OK;
 }
 
-extern "C" int pareben_ctx_launch_info(pareben_ctx *c, int64_t info[4])
+extern "C" int pareben_ctx_launch_info(pareben_ctx *c, int64_t info[5])
 {
     if (!c || !info) return fail(PAREBEN_EINVAL, "bad argument");
-    for (int i = 0; i < 4; i++) info[i] = c->launch_info[i];
+    for (int i = 0; i < 5; i++) info[i] = c->launch_info[i];
     return PAREBEN_OK;
 }
 
@@ -1154,7 +1144,7 @@ static int fit_one(int prior, int epis, const double *basis, const double *targe
     if (prior == PAREBEN_PRIOR_GAUSSIAN) {
         FitParams P;
         P.F = F; P.lambda = lambda; P.alpha = alpha; P.Beta = d_beta; P.scalars = d_sc; P.status = d_st; P.counters = d_cnt;
-        P.ws = c->d_ws; P.offK = c->L.offK; P.offSig = c->L.offSig; P.offM = c->L.offM; P.K = c->kfull; P.cap = c->cap;
+        P.ws = c->d_ws; P.offK = c->L.offK; P.offSig = c->L.offSig; P.offM = c->L.offM; P.K = c->kfull; P.cap = c->cap; P.cap_flag = c->cap_ref;
         P.p = k; P.v = c->variant;
         CK(hipFuncSetAttribute((const void *)gm_fit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FIT_BYTES));
         hipLaunchKernelGGL(gm_fit_kernel, dim3(1), dim3(FIT_THREADS), LDS_FIT_BYTES, c->stream, P);

@@ -40,11 +40,12 @@ struct GmVariant {
 struct FitCounters {
     int64_t n_outer, n_inner, n_add, n_del, n_reest, n_fullstat;
     int64_t sum_m_action, sum_m_full, sum_m2_full, m_final, m_max, status;
+    int64_t mfma_tiles;   // 16 x 16 x 16 tile products (4 x v_mfma_f64_16x16x4_f64, 8192 flop) the fit's matrix-core passes execute
 };
-#define PAREBEN_NCOUNTERS 12
+#define PAREBEN_NCOUNTERS 13
 
 enum {
-    ST_OVERFLOW = 1,      // active set reached the workspace capacity
+    ST_OVERFLOW = 1,      // active set exceeded the reference's basisMax (and, with ST_ABORT, the workspace capacity)
     ST_CHOLESKY = 2,      // Hessian not positive definite
     ST_STALE = 4,         // reference's stale-index delete path taken (SURVEY.md hard parts)
     ST_ABORT = 8          // fit stopped early (a state the reference leaves undefined)
@@ -67,6 +68,7 @@ struct GmWork {
     int priv_base, priv_rows;                              // this workgroup's private rows (pool exhausted)
     double *e;                                             // max(N) scratch
     int cap, ld;
+    int cap_flag;      // the reference's basisMax: an active set growing past it is flagged (ST_OVERFLOW), the fit goes on up to cap
 };
 
 // One feature-parallel phase of a fit offered to idle workgroups (gm_fit.h, "shared phases").  `word` packs

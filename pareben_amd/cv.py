@@ -2,6 +2,8 @@
 (R/CrossValidate.R:61-117) for the global grid search: same arguments, same returned object
 (``Results.Detail``, ``Results.Summary``, ``lambda.optimal``, ``alpha.optimal``), with the
 nFolds x alpha x lambda fits evaluated by the HIP library instead of a foreach backend."""
+import warnings
+
 import numpy as np
 
 from . import _lib
@@ -60,6 +62,14 @@ def CrossValidate(BASIS, Target, nFolds, foldId=0, Epis="no", prior="gaussian", 
         fold_err, status = err_local, st_local
     stats["status"] = status
     stats["counters"] = cnt_local
+    n_stopped = int(np.sum((status & _lib.ST_ABORT) != 0))
+    n_flagged = int(np.sum((status & _lib.ST_OVERFLOW) != 0))
+    stats["stopped_fits"], stats["fits_past_reference_capacity"] = n_stopped, n_flagged
+    if n_stopped:
+        # a stopped fit (workspace capacity, non-SPD Hessian: states the reference leaves undefined) scores NaN; its cell
+        # is left out of the arg-min like an NA in R's which.min -- say so instead of doing it silently
+        warnings.warn("%d of %d fits were stopped early (status bit 8) and score NaN; %d cell(s) are excluded from the arg-min"
+                      % (n_stopped, status.size, int(np.sum(np.any((status & _lib.ST_ABORT) != 0, axis=1)))), RuntimeWarning)
 
     col = "MSE" if prior == "gaussian" else "logL"
     detail = _frame({

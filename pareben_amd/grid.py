@@ -104,4 +104,8 @@ def summarise_cv(alpha, lam, fold_err, nFolds, prior="gaussian"):
         if v < best:
             best = v
             idx = i
+    if idx < 0:
+        # R's which.min() would return integer(0) here and CrossValidate() would hand back empty optima; a table
+        # without a single complete cell (every cell has a stopped fit, status bit 8) is an error, not an answer
+        raise ValueError("no (alpha, lambda) cell has a complete set of fold scores: every cell holds a stopped fit")
     return alpha[order], lam[order], se, err, idx

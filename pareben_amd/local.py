@@ -14,6 +14,7 @@ full-length ``foldId`` is passed (R/LocalSearch.R:13-20), so its result is not r
 folds come from ``AssignToFolds`` (``set.seed(1)``, as in the global search) unless ``foldId`` is given.
 The binomial prior is refused with the reference's own message (:137)."""
 import math
+import warnings
 
 import numpy as np
 
@@ -42,6 +43,8 @@ def replay_local_search(alpha_desc, lam_desc, fold_err_of):
             previous = sse[mi, 0] + sse[mi, 1]
             e = np.asarray(fold_err_of(ia, il), dtype=np.float64)
             mean, se = float(np.mean(e)), r_sd(e) / math.sqrt(len(e))
+            if not math.isfinite(mean):                           # a stopped fit (NaN score): the cell counts as "no improvement"
+                mean, se = math.inf, 0.0                          # (R's which.min / if() would stop with an error on the NA)
             sse[il] = (mean, se)
             msecv[step] = (a, lam, mean, se)
             visited.append((ia, il))
@@ -65,6 +68,9 @@ def LocalSearch(BASIS, Target, nFolds, Epis="no", foldId=0, prior="gaussian", de
     folds = AssignToFolds(X, nFolds, foldId, sample_kind=sample_kind)
     with _lib.Context(X, y, folds, nFolds, prior="gaussian", epis=(Epis == "yes"), device=device) as ctx:
         fold_err, status, _ = ctx.run(alpha, lam)
+    if np.any((status & _lib.ST_ABORT) != 0):
+        warnings.warn("%d fits were stopped early (status bit 8) and score NaN; their cells end the walk of their alpha"
+                      % int(np.sum((status & _lib.ST_ABORT) != 0)), RuntimeWarning)
     a_desc = np.unique(alpha)[::-1]
     l_desc = np.unique(lam)[::-1]
     cell = {(float(a), float(l)): i for i, (a, l) in enumerate(zip(alpha, lam))}

@@ -77,7 +77,7 @@ struct Work {
         W.Sig = sig.data(); W.H = sig.data() + (size_t)cap * cap;
         d = md.data(); int c1 = cap + 1;
         W.A = d; d += c1; W.mu = d; d += c1; W.gam = d; d += c1; W.v1 = d; d += c1; W.v2 = d; d += c1; W.v3 = d; d += c1; W.v4 = d;
-        W.used = used.data(); rowid.assign(cap + 1, 0); W.rowid = rowid.data(); pfree.assign(cap + 2, 0); W.pfree = pfree.data(); W.priv_base = 0; W.priv_rows = 0; W.vb = nullptr; W.bsc = nullptr; W.e = nullptr; W.cap = cap; W.ld = cap;
+        W.used = used.data(); rowid.assign(cap + 1, 0); W.rowid = rowid.data(); pfree.assign(cap + 2, 0); W.pfree = pfree.data(); W.priv_base = 0; W.priv_rows = 0; W.vb = nullptr; W.bsc = nullptr; W.e = nullptr; W.cap = cap; W.ld = cap; W.cap_flag = cap;
     }
 };
 }  // namespace

@@ -43,6 +43,12 @@ def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
+def set_capacity_policy(continue_past_basismax=False, ref_cap_override=0):
+    """(False, 0): the reference's behaviour (a fit needing more than basisMax columns is stopped);
+    (True, r): the HIP build's flag-and-continue policy, basisMax lowered to r when r > 0."""
+    lib().eben_set_capacity_policy(int(bool(continue_past_basismax)), int(ref_cap_override))
+
+
 def fit_gaussian(X, y, lam, alpha, epis=False):
     """-> dict(Beta (n_eff x 4|5), wald, intercept, residual, counters, rc)"""
     X = np.asfortranarray(X, dtype=np.float64)

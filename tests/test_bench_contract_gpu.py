@@ -27,7 +27,7 @@ def _run(extra_args, extra_env=None):
 
 
 def test_bench_json_contract_and_collective_path():
-    r = _run(["--cpu-sample", "3"])
+    r = _run(["--cpu-budget-s", "1"])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in r, k
@@ -36,10 +36,16 @@ def test_bench_json_contract_and_collective_path():
     assert "workload" in r["config"] and "rehearsal" in r["config"]["workload"]     # not the BASELINE size: labelled as such
     assert r["config"]["fits_per_step"] == 4 * 6 * 3
     assert abs(r["value"] - r["config"]["fits_per_step"] / (r["ms_per_step"] * 1e-3)) < 1e-6 * r["value"]
+    c = r["config"]
+    assert c["wall_from_entry_s"] >= c["setup_s"]["ctx_create"] + c["setup_s"]["first_run"] > 0
+    assert c["aborted_fits"] == 0
     ro = r["roofline"]
-    assert ro["bound"] == "hbm" and ro["unit"] == "GB/s" and ro["peak"] == 8000.0 and ro["kernel"] == "gm_cv_kernel"
+    assert ro["bound"] in ("hbm", "mfma") and ro["kernel"].startswith(("gm_cv_kernel", "gram_kernel"))
+    assert (ro["unit"], ro["peak"]) in (("GB/s", 8000.0), ("TFLOP/s", 78.6))
     assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-12 and ro["achieved"] > 0
     assert ro["traffic"] is None                                    # PMC traffic is attached to the profiled workload only
+    fk = ro if "mfma" in ro else ro["fit_kernel"]
+    assert fk["mfma"]["executed_mfma_flops_per_launch"] > 0 and fk["hbm"]["algorithmic_bytes_per_launch"] > 0
     cb = r["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "fits/s" and cb["value"] > 0 and cb["cores"] >= 1 and "sample" in cb
     d = _run(["--cpu-baseline", "0"], {"PAREBEN_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533",
@@ -47,3 +53,22 @@ def test_bench_json_contract_and_collective_path():
     for k in ("alpha_opt", "lambda_opt", "cv_error", "aborted_fits"):
         assert d["config"][k] == r["config"][k], k                  # bit-identical through the all-gather
     assert "cpu_baseline" not in d
+
+
+def test_bench_gpus_flag_is_honoured():
+    """--gpus must agree with the launcher's WORLD_SIZE (a mismatch is an error, not a silent one-GPU run)."""
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29534")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL, cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert p.returncode == 2 and b"WORLD_SIZE" in p.stderr
+
+
+def test_bench_binomial_workload():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "config3", "--steps", "1", "--warmup", "0",
+                        "--cpu-baseline", "0"], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    r = json.loads([l for l in p.stdout.decode().splitlines() if l.strip()][-1])
+    assert r["config"]["fits_per_step"] == 2000 and "configs[2]" in r["config"]["workload"]
+    ro = r["roofline"]
+    assert ro["bound"] == "hbm" and ro["kernel"] == "bm_cv_kernel" and ro["achieved"] > 0
+    assert abs(r["config"]["alpha_opt"] - 0.2) < 1e-12 and abs(r["config"]["lambda_opt"] - 0.014589761289879953) < 1e-15

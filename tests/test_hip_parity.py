@@ -105,10 +105,12 @@ def test_rerun_is_bit_identical_and_order_free(golden):
 
 
 def test_gram_kernel_vs_numpy(golden):
-    """gram_kernel (FP64 matrix cores, lower-triangle blocks + mirrored store) against numpy.
-    Integer-valued designs (BASIS is {-1, 0, 1}): X'X is exact, so G[u][i] = D * (1/|x_u|) / |x_i| must
-    agree bit for bit.  Gaussian design with ragged sizes (K not a multiple of the 128-block, N not a
-    multiple of the 16-sample slab): to rounding, and exactly symmetric before scaling."""
+    """gram_kernel (FP64 matrix cores) against the reference's own operation order, restated in numpy:
+    BASIS_PHI[u][i] = (sum over samples, in order, of x_i[h] * (x_u[h] / |x_u|)) / |x_i|
+    (elasticNetLinearNeMainEff.c:1171-1177, :1608-1630).  For integer-coded designs (BASIS is {-1, 0, 1}) every
+    product is exact, so the fma chain of the matrix cores must reproduce that sequential sum bit for bit.
+    Gaussian design with ragged sizes (K not a multiple of the 128-block, N not a multiple of the 16-sample
+    slab): to rounding."""
     X = golden.BASIS[:, :481]
     g = golden.basis481
     fid = g["fold_id"]
@@ -118,8 +120,11 @@ def test_gram_kernel_vs_numpy(golden):
             Xt = X[fid != f + 1]
             q = np.sum(Xt * Xt, axis=0); q[q == 0] = 1.0
             sc = np.sqrt(q)
-            D = Xt.T @ Xt                                           # exact in float64 (small integers)
-            want = (D * (1.0 / sc)[:, None]) / sc[None, :]
+            phi = Xt / sc[None, :]
+            acc = np.zeros((481, 481))
+            for h in range(Xt.shape[0]):                             # sequential over samples, like the reference's ddot
+                acc += phi[h][:, None] * Xt[h][None, :]
+            want = acc / sc[None, :]
             assert np.array_equal(Gd, want)
     rng = np.random.default_rng(2)
     n, p = 203, 333
@@ -133,8 +138,6 @@ def test_gram_kernel_vs_numpy(golden):
     sc = np.sqrt(q)
     want = (Xt.T @ Xt) / sc[:, None] / sc[None, :]
     assert np.abs(Gd - want).max() < 1e-13
-    Dd = Gd * sc[:, None] * sc[None, :]
-    assert np.abs(Dd - Dd.T).max() < 1e-12 * np.abs(Dd).max()
     assert np.all(Gd[7] == 0) and np.all(Gd[:, 7] == 0)
 
 
@@ -265,10 +268,46 @@ def test_epistasis_vs_golden(golden):
     assert abs(np.min(np.asarray(S["MSE"])) - k["cv_error"]) < REL_CV * k["cv_error"]
     with pareben_amd.Context(X, g["y_scaled"], g["fold_id"], 5, epis=True) as ctx:
         E2, st, cnt = ctx.run(g["alpha_scaled"], g["lam_scaled"])
-    ok = (st & 8) == 0                                # capacity aborts mirror the oracle's (reference: heap overflow)
+    # the reference's basisMax here is 2K = 120: the fixture (oracle with the reference's policy) has no score for
+    # the small-lambda fits that need more; the HIP path flags those (bit 0) and lets them continue to
+    # min(N_train, 1024) = 160 columns -- compared in test_flag_and_continue_past_reference_capacity
     ref = g["fold_err_scaled"]
-    assert ok.mean() > 0.3                            # capacity 2K = 120 is hit by the small-lambda cells
+    ok = (st & 9) == 0
+    assert ok.mean() > 0.3
     assert _rel(E2[ok], ref[ok]).max() < 1e-8
+    assert np.all(np.isfinite(E2[(st & 8) == 0])) and ((st & 1) != 0).sum() > 0
+
+
+def test_flag_and_continue_past_reference_capacity(golden, oracle, monkeypatch):
+    """Capacity policy (include/pareben_hip.h, pareben_ctx_create): a fit that outgrows the reference's basisMax
+    is flagged (status bit 0) and continues in the larger workspace instead of being dropped; it is stopped (bit 3)
+    only at the workspace capacity.  PAREBEN_REF_CAP lowers basisMax so that small problems take the path; the oracle
+    runs the same policy.  Same scores, same flags, same event counts."""
+    X, y = golden.BASIS[:150, :200], golden.y[:150]
+    fid = AssignToFolds(X, 3)
+    alpha, lam = BuildGrid(X, y, 3)
+    sel = np.arange(2, 400, 7)
+    monkeypatch.setenv("PAREBEN_REF_CAP", "12")
+    with pareben_amd.Context(X, y, fid, 3) as ctx:
+        E, st, cnt = ctx.run(alpha[sel], lam[sel])
+        info = ctx.launch_info()
+    assert info["reference_capacity"] == 12 and info["capacity"] == 200        # max(basisMax = K = 200, min(N_train, 1024))
+    oracle.set_capacity_policy(True, 12)
+    try:
+        Eo, co, rc = oracle.cv_grid(X, y, fid, 3, alpha[sel], lam[sel])
+    finally:
+        oracle.set_capacity_policy(False, 0)
+    flagged = (st & 1) != 0
+    assert flagged.sum() > 20 and np.all((st & 8) == 0)                        # many fits outgrow 12 columns, none is stopped
+    assert cnt[..., 10].max() > 12
+    assert _rel(E, Eo).max() < 1e-8
+    assert cnt[..., 2].sum() == co["n_add"] and cnt[..., 3].sum() == co["n_del"] and cnt[..., 4].sum() == co["n_reest"]
+    assert co["status"] & 1
+    # a hard limit below what the fits need: stopped fits score NaN and are reported, the rest is unchanged
+    with pareben_amd.Context(X, y, fid, 3, max_active=12) as ctx:
+        E2, st2, _ = ctx.run(alpha[sel], lam[sel])
+    stopped = (st2 & 8) != 0
+    assert np.array_equal(stopped, flagged) and np.all(np.isnan(E2[stopped])) and np.array_equal(E2[~stopped], E[~stopped])
 
 
 def test_lazy_gram_rows_vs_full_matrix_and_golden(golden, monkeypatch):
@@ -323,8 +362,12 @@ def test_lazy_gram_rows_epistasis(golden, monkeypatch):
     with pareben_amd.Context(X, g["y_scaled"], g["fold_id"], 5, epis=True) as ctx:
         El, stl, _ = ctx.run(g["alpha_scaled"], g["lam_scaled"])
     assert np.array_equal(stl, stf)
-    ok = (stl & 8) == 0
+    ok = (stl & 9) == 0
     assert _rel(El[ok], Ef[ok]).max() < 1e-8
+    # fits past the reference's capacity (120 columns) run on to as many columns as training rows (160): nearly singular
+    # systems, on which the two modes' different summation order of a Gram row shows (observed 1e-6)
+    big = (stl & 9) == 1
+    assert big.sum() > 0 and _rel(El[big], Ef[big]).max() < 1e-4
 
 
 def test_shared_phases_bit_identical(oracle, monkeypatch):

@@ -37,9 +37,15 @@ rep = {"n": n, "p": p, "n_folds": nf, "cells": int(len(sel)), "fits": int(E.size
        "m_max": int(cnt[..., 10].max()), "m_final_mean": float(cnt[..., 9].mean()),
        "n_add_total": int(cnt[..., 2].sum()), "n_inner_total": int(cnt[..., 1].sum()),
        "fits_per_s": E.size / (tim["total_ms"] / 1e3)}
-cv = E.sum(axis=1) / n
-best = int(np.argmin(cv))
-rep["best_cell"] = {"alpha": float(alpha[sel][best]), "lambda": float(lam[sel][best]), "cv_error": float(cv[best])}
+cv = E.mean(axis=1)                                      # Results.Summary$MSE = mean of the fold SSEs; NaN where a fit was stopped
+rep["cells_with_stopped_fits"] = int(np.isnan(cv).sum())
+if np.all(np.isnan(cv)):
+    rep["best_cell"] = None
+else:
+    best = int(np.nanargmin(cv))
+    rep["best_cell"] = {"alpha": float(alpha[sel][best]), "lambda": float(lam[sel][best]), "cv_error": float(cv[best])}
+rep["flagged_past_basisMax"] = int(((st & 1) != 0).sum())
+rep["m_max_by_lambda_index"] = {int(l): int(cnt[..., 10].reshape(len(ai), len(li), nf)[:, j, :].max()) for j, l in enumerate(li)}
 print(json.dumps(rep), flush=True)
 if n_or > 0:
     import oracle_lib

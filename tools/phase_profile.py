@@ -35,7 +35,7 @@ names = ["fullstat_features", "fullstat_rest(incl in total only)", "delta_ml+col
          "act_matvec", "act_rank1", "act_refresh", "h_build", "mu_after_inv", "batch_track", "inv_pivot", "inv_tn"]
 tot = ph[:, 7].sum()
 print("sum of per-fit wall ticks (100 MHz): %.3f s over %d fits" % (tot / 1e8, len(ph)))
-cc = cnt.reshape(-1, 12).astype(np.float64)
+cc = cnt.reshape(-1, cnt.shape[-1]).astype(np.float64)
 print("aggregate full-stat rate per CU: %.1f GFLOP/s (peak 307); action Gram-row rate per CU: %.1f GB/s" % (
     2.0 * a.p * cc[:, 8].sum() / (ph[:, 0].sum() / 1e8) / 1e9, 8.0 * a.p * cc[:, 6].sum() / (ph[:, 3].sum() / 1e8) / 1e9))
 print("shader clock during the full-stat pass: %.0f MHz" % (ph[:, 1].sum() / ph[:, 0].sum() * 100.0))
@@ -47,7 +47,7 @@ print("  shared jobs: full-stat chunks %d (owner ran %.0f %%, waited %.2f s); sw
     ph[:, 19].sum(), 100 * ph[:, 18].sum() / max(ph[:, 19].sum(), 1), ph[:, 21].sum() / 1e8))
 heavy = np.argsort(ph[:, 7])[-5:]
 for u in heavy:
-    c = cnt.reshape(-1, 12)[u]
+    c = cnt.reshape(-1, cnt.shape[-1])[u]
     fs_s = ph[u, 0] / 1e8
     print("  fit %d: %.3f s  M=%d inner=%d adds=%d fullstat=%d sumM2=%.3g fs_rate=%.1f GF/s act_GBs=%.1f | " % (u, ph[u, 7] / 1e8, c[9], c[1], c[2], c[5], c[8], 2.0 * a.p * c[8] / fs_s / 1e9, 8.0 * a.p * c[6] / (ph[u, 3] / 1e8) / 1e9),
           "fs_own=%.0f%% sq_own=%.0f%% fs_wait=%.2fs sq_wait=%.2fs " % (100 * ph[u, 16] / max(ph[u, 17], 1), 100 * ph[u, 18] / max(ph[u, 19], 1), ph[u, 20] / 1e8, ph[u, 21] / 1e8) +
