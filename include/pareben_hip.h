@@ -36,7 +36,7 @@ extern "C" {
 #define PAREBEN_EINVAL       -1   /* bad argument                                   */
 #define PAREBEN_EHIP         -2   /* HIP runtime error (see pareben_last_error)     */
 #define PAREBEN_ENOMEM       -3   /* device workspace does not fit                  */
-#define PAREBEN_EUNSUPPORTED -4   /* binomial + epistasis is not built               */
+#define PAREBEN_EUNSUPPORTED -4   /* not available in this build / on this machine   */
 
 #define PAREBEN_PRIOR_GAUSSIAN 0
 #define PAREBEN_PRIOR_BINOMIAL 1
@@ -123,6 +123,22 @@ int pareben_cv_grid(const double *basis, int n, int p, const double *target,
                     const double *alpha, const double *lambda, int n_cells,
                     int epis, int prior, int device,
                     double *fold_err, int32_t *status, int64_t *counters);
+
+/*
+ * The same grid on n_gpu devices of one node from ONE host process (the caller is a single R session;
+ * reference call site: the foreach over grid rows, R/CrossValidate.R:66-70, whose workers were separate R
+ * processes): one host thread and context per device, BASIS / Target / fold ids replicated, the cells dealt
+ * round-robin over the cost-sorted list, and the path's only exchange -- one grouped ncclAllGather (RCCL over
+ * xGMI, ncclCommInitAll communicators) of the device-resident per-cell results, after which every GPU holds
+ * the whole table and the host copies it from device 0.  n_gpu <= 0 uses every visible device.  Results are
+ * bit-identical for any n_gpu (a fit's arithmetic does not depend on what else runs).  RCCL is bound at
+ * run time: without librccl.so this entry returns PAREBEN_EUNSUPPORTED and everything else still works.
+ */
+int pareben_cv_grid_multi(const double *basis, int n, int p, const double *target,
+                          const int32_t *fold_id, int n_folds,
+                          const double *alpha, const double *lambda, int n_cells,
+                          int epis, int prior, int n_gpu,
+                          double *fold_err, int32_t *status, int64_t *counters);
 
 /*
  * One fit on all rows, same argument tuple as the reference's .C entry

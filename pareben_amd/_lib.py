@@ -40,6 +40,7 @@ def load():
     L.pareben_ctx_destroy.argtypes = [C.c_void_p]
     L.pareben_ctx_gram.argtypes = [C.c_void_p, C.c_int, dp]
     L.pareben_cv_grid.argtypes = [dp, C.c_int, C.c_int, dp, ip, C.c_int, dp, dp, C.c_int, C.c_int, C.c_int, C.c_int, dp, ip, lp]
+    L.pareben_cv_grid_multi.argtypes = L.pareben_cv_grid.argtypes
     L.pareben_fit_gaussian.argtypes = [dp, dp, C.c_double, C.c_double, dp, dp, dp, C.c_int, C.c_int, C.c_int, dp, C.c_int, lp]
     L.pareben_fit_gaussian_epis.argtypes = L.pareben_fit_gaussian.argtypes
     L.pareben_fit_binomial.argtypes = [dp, dp, C.c_double, C.c_double, dp, dp, dp, dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, lp]
@@ -128,6 +129,27 @@ class Context:
             self.close()
         except Exception:
             pass
+
+
+def cv_grid_multi(BASIS, Target, fold_id, n_folds, alpha, lam, prior="gaussian", epis=False, n_gpu=0, want_counters=True):
+    """pareben_cv_grid_multi: the grid on n_gpu devices from this one process (one host thread + context per device,
+    one RCCL all-gather of the per-cell results); n_gpu <= 0 = every visible device.
+    -> (fold_err [n_cells, n_folds], status, counters | None)"""
+    L = load()
+    X = np.asfortranarray(BASIS, dtype=np.float64)
+    y = np.ascontiguousarray(Target, dtype=np.float64).reshape(-1)
+    fid = np.ascontiguousarray(fold_id, dtype=np.int32).reshape(-1)
+    alpha = np.ascontiguousarray(alpha, dtype=np.float64).reshape(-1)
+    lam = np.ascontiguousarray(lam, dtype=np.float64).reshape(-1)
+    n, p = X.shape
+    nc = alpha.shape[0]
+    err = np.empty((nc, n_folds))
+    st = np.empty((nc, n_folds), dtype=np.int32)
+    cnt = np.zeros((nc, n_folds, NCOUNTERS), dtype=np.int64) if want_counters else None
+    _chk(L.pareben_cv_grid_multi(_dp(X), n, p, _dp(y), _ip(fid), int(n_folds), _dp(alpha), _dp(lam), nc,
+                                 1 if epis else 0, 0 if prior == "gaussian" else 1, int(n_gpu),
+                                 _dp(err), _ip(st), _lp(cnt) if cnt is not None else None), "pareben_cv_grid_multi")
+    return err, st, cnt
 
 
 def fit_gaussian(BASIS, Target, lam, alpha, device=0, epis=False):

@@ -18,6 +18,9 @@
 #include <algorithm>
 #include <numeric>
 #include <string>
+#include <thread>
+#include <dlfcn.h>
+#include <rccl/rccl.h>           // types and prototypes only: the library is bound at run time (rccl_load)
 
 #ifndef FIT_THREADS
 #define FIT_THREADS 512          // 8 wavefronts per fit workgroup: 256 VGPRs per lane for the matrix-core pass
@@ -104,9 +107,10 @@ __device__ __forceinline__ double block_sum_256(double v, double *sh)
 
 // per column: scale = |x| (1 when 0), rscale, bt0 = x.y/scale, cs = x.1/scale
 // (elasticNetLinearNeMainEff.c:87-99 and the y- and 1-parts of :1171-1177)
+// phi (optional): the normalised column x / scale (the reference's PHI, :1608-1617), the u-operand of gram_kernel
 __global__ void colstats_kernel(const double *__restrict__ X, const double *__restrict__ y, int N,
                                 double *__restrict__ scale, double *__restrict__ rscale,
-                                double *__restrict__ bt0, double *__restrict__ cs)
+                                double *__restrict__ bt0, double *__restrict__ cs, double *__restrict__ phi)
 {
     __shared__ double sh[16];
     const int j = blockIdx.x;
@@ -123,6 +127,10 @@ __global__ void colstats_kernel(const double *__restrict__ X, const double *__re
         if (q == 0) q = 1;
         const double s = sqrt(q);
         scale[j] = s; rscale[j] = 1 / s; bt0[j] = xy / s; cs[j] = x1 / s;
+    }
+    if (phi) {
+        const double s = sqrt(q == 0 ? 1.0 : q);                // q is the same in every thread (block_sum_256)
+        for (int h = threadIdx.x; h < N; h += blockDim.x) phi[(size_t)j * N + h] = x[h] / s;
     }
 }
 
@@ -143,8 +151,9 @@ __global__ void ystats_kernel(const double *__restrict__ y, int N, double *__res
 // Normalised Gram matrix of one fold: G[u*K + i] = ( sum_h X[h,i] * (X[h,u] / scale[u]) ) / scale[i], i.e. the
 // reference's BASIS_PHI row of basis u (PHI = x_u/|x_u| dotted with every column, then divided by that
 // column's norm: elasticNetLinearNeMainEff.c:1171-1177, :1608-1630) for every u at once.
-//   * Same operations in the same order as the reference's sequential dot product: the u-operand is divided by
-//     its norm when it is staged, and a 16 x 16 accumulator tile of v_mfma_f64_16x16x4_f64 is ONE fma chain
+//   * Same operations in the same order as the reference's sequential dot product: the u-operand is the column
+//     divided by its norm (colstats_kernel writes that copy, Phi: a division in this kernel's staging loop took a
+//     quarter of the matrix pipe's time -- FP64 vector ops take turns with it), and a 16 x 16 accumulator tile of v_mfma_f64_16x16x4_f64 is ONE fma chain
 //     over the samples h in ascending order (the matrix op rounds like four chained fmas,
 //     tools/ubench/mfma_f64_order.hip).  For integer-coded designs (genotypes: -1/0/1) every product is exact,
 //     so G equals the reference's values bit for bit -- which is what keeps the long add/delete trajectories of
@@ -165,7 +174,7 @@ __global__ void ystats_kernel(const double *__restrict__ y, int N, double *__res
 #define GS 16
 #define GP 17
 typedef double gd4 __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256, 2) void gram_kernel(const double *__restrict__ X, int N, int K,
+__global__ __launch_bounds__(256, 2) void gram_kernel(const double *__restrict__ X, const double *__restrict__ Phi, int N, int K,
                                                       const double *__restrict__ scale,
                                                       double *__restrict__ G, int nb, int n_blocks)
 {
@@ -180,9 +189,6 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const double *__restrict__
     const int wu = wave >> 1, wi = wave & 1;
     // staging: thread -> sample h = tid & 15 of columns (tid >> 4) + 16 q
     const int sh = tid & 15, sc = tid >> 4;
-    double su[8];
-#pragma unroll
-    for (int q = 0; q < 8; q++) { const int cu = u0 + sc + 16 * q; su[q] = cu < K ? scale[cu] : 1.0; }
     gd4 acc[4][4];
 #pragma unroll
     for (int a = 0; a < 4; a++)
@@ -194,14 +200,14 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const double *__restrict__
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             const int cu = u0 + sc + 16 * q, ci = i0 + sc + 16 * q;
-            ra[q] = (hh < N && cu < K) ? X[(size_t)cu * N + hh] : 0.0;
+            ra[q] = (hh < N && cu < K) ? Phi[(size_t)cu * N + hh] : 0.0;
             rb[q] = (hh < N && ci < K) ? X[(size_t)ci * N + hh] : 0.0;
         }
     };
     auto stash = [&](int buf) {
 #pragma unroll
         for (int q = 0; q < 8; q++) {
-            sm[buf][0][(sc + 16 * q) * GP + sh] = ra[q] / su[q];   // PHI = x_u / |x_u|  (:1608-1617)
+            sm[buf][0][(sc + 16 * q) * GP + sh] = ra[q];             // PHI = x_u / |x_u|, formed by colstats_kernel
             sm[buf][1][(sc + 16 * q) * GP + sh] = rb[q];
         }
     };
@@ -702,6 +708,7 @@ struct pareben_ctx {
     int kfull = 0;          // columns the fit sees: p, or p(p+1)/2 with epistasis
     GmVariant variant{};
     double *d_basis = nullptr, *d_y = nullptr;
+    double *d_phi = nullptr;   // max(N_train) x K scratch: the normalised design of the fold whose Gram matrix is being built
     std::vector<FoldHost> folds;
     FoldDev *d_folds = nullptr;
     hipStream_t stream = nullptr;
@@ -757,7 +764,7 @@ extern "C" int pareben_ctx_destroy(pareben_ctx *c)
         hipFree(f.d_tr); hipFree(f.d_te); hipFree(f.X); hipFree(f.y); hipFree(f.Xte); hipFree(f.yte);
         hipFree(f.scale); hipFree(f.rscale); hipFree(f.bt0); hipFree(f.cs); hipFree(f.G); hipFree(f.ystat);
     }
-    hipFree(c->d_basis); hipFree(c->d_y); hipFree(c->d_folds); hipFree(c->d_ws); hipFree(c->d_lazy); hipFree(c->d_rows);
+    hipFree(c->d_basis); hipFree(c->d_y); hipFree(c->d_phi); hipFree(c->d_folds); hipFree(c->d_ws); hipFree(c->d_lazy); hipFree(c->d_rows);
     for (auto &e : c->ev) if (e) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -835,7 +842,8 @@ static int ctx_create_impl(pareben_ctx **out, int device, const double *basis, i
         const size_t row_b = KF * sizeof(double);
         const char *force = getenv("PAREBEN_GRAM_ROWS");
         const long long forced = force ? atoll(force) : 0;
-        if (forced > 0 || (size_t)n_folds * KF * row_b > avail) {
+        const size_t phi_b = (size_t)n_train_max * row_b;      // scratch of gram_kernel's normalised operand
+        if (forced > 0 || (size_t)n_folds * KF * row_b + phi_b > avail) {
             c->lazy = 1;
             long long priv = std::min<long long>(c->cap, (long long)(avail / 4 / ((size_t)c->max_blocks * row_b)));
             long long rows = (long long)((avail - (size_t)priv * c->max_blocks * row_b) / ((size_t)n_folds * row_b));
@@ -851,6 +859,7 @@ static int ctx_create_impl(pareben_ctx **out, int device, const double *basis, i
             CK(dmalloc(&c->d_lazy, (size_t)c->lazy_hdr + (size_t)n_folds * KF));
         } else {
             for (int f = 0; f < n_folds; f++) CK(dmalloc(&c->folds[f].G, KF * KF));
+            CK(dmalloc(&c->d_phi, (size_t)n_train_max * KF));
         }
     }
     for (int f = 0; f < n_folds; f++) {
@@ -898,13 +907,14 @@ static int prepare_folds(pareben_ctx *c)
         }
         hipLaunchKernelGGL(gather_kernel, dim3((H.N + 255) / 256), dim3(256), 0, c->stream, c->d_y, H.d_tr, H.N, H.y);
         if (H.nte) hipLaunchKernelGGL(gather_kernel, dim3((H.nte + 255) / 256), dim3(256), 0, c->stream, c->d_y, H.d_te, H.nte, H.yte);
-        hipLaunchKernelGGL(colstats_kernel, dim3(kf), dim3(256), 0, c->stream, H.X, H.y, H.N, H.scale, H.rscale, H.bt0, H.cs);
+        hipLaunchKernelGGL(colstats_kernel, dim3(kf), dim3(256), 0, c->stream, H.X, H.y, H.N, H.scale, H.rscale, H.bt0, H.cs,
+                           H.G ? c->d_phi : (double *)nullptr);
         hipLaunchKernelGGL(ystats_kernel, dim3(1), dim3(256), 0, c->stream, H.y, H.N, H.ystat);
         if (H.G) {                                  // 128 x 128 blocks, dealt to the XCDs in contiguous ranges of the row-major list
             const int nb = (kf + GB - 1) / GB;
             const long long nbl = (long long)nb * nb;
             const int per = (int)((nbl + 7) / 8);
-            hipLaunchKernelGGL(gram_kernel, dim3(per * 8), dim3(256), 0, c->stream, H.X, H.N, kf, H.scale, H.G, nb, (int)nbl);
+            hipLaunchKernelGGL(gram_kernel, dim3(per * 8), dim3(256), 0, c->stream, H.X, c->d_phi, H.N, kf, H.scale, H.G, nb, (int)nbl);
         }
         // ymean / varY live inside the FoldDev record: copy the two doubles device-to-device
         HIPCHK(hipMemcpyAsync((char *)(c->d_folds + f) + offsetof(FoldDev, ymean), H.ystat, 2 * sizeof(double),
@@ -946,10 +956,29 @@ static int ensure_workspace(pareben_ctx *c, int blocks)
     return PAREBEN_OK;
 }
 
-extern "C" int pareben_ctx_run(pareben_ctx *c, int n_cells, const double *alpha, const double *lambda,
-                               double *fold_err, int32_t *status, int64_t *counters)
+// Device-side state of one launch: everything run_enqueue() puts on the context's stream; the results stay in
+// HBM until the caller copies them (pareben_ctx_run) or hands them to the all-gather (pareben_cv_grid_multi).
+struct RunDev {
+    double *d_alpha = nullptr, *d_lambda = nullptr, *d_err = nullptr;
+    int *d_order = nullptr, *d_queue = nullptr, *d_status = nullptr;
+    long long *d_cnt = nullptr, *d_phase = nullptr;
+    FsJob *d_jobs = nullptr; int *d_active = nullptr;
+    std::vector<int> order;                  // host copies the async H2D transfers read: alive until the stream is synchronised
+    int act_host[4] = {0, 0, 0, 0};
+    int n_units = 0, blocks = 0;
+    void release()
+    {
+        hipFree(d_jobs); hipFree(d_active); hipFree(d_phase); hipFree(d_alpha); hipFree(d_lambda); hipFree(d_err);
+        hipFree(d_order); hipFree(d_queue); hipFree(d_status); hipFree(d_cnt);
+        d_jobs = nullptr; d_active = nullptr; d_phase = nullptr; d_alpha = d_lambda = d_err = nullptr;
+        d_order = d_queue = d_status = nullptr; d_cnt = nullptr;
+    }
+};
+
+// Enqueue one grid evaluation on the context's stream: parameter upload, per-fold preparation, the persistent fit
+// kernel.  Events ev[0..2] bracket preparation and fit.  Nothing is synchronised here.
+static int run_enqueue(pareben_ctx *c, int n_cells, const double *alpha, const double *lambda, bool want_counters, RunDev &D)
 {
-    if (!c || n_cells < 1 || !alpha || !lambda || !fold_err) return fail(PAREBEN_EINVAL, "bad argument");
     HIPCHK(hipSetDevice(c->device));
     const int nF = c->n_folds, n_units = n_cells * nF;
     // Queue order.  Cost is far from monotone in lambda: nothing happens above the lambda where the first
@@ -966,8 +995,8 @@ extern "C" int pareben_ctx_run(pareben_ctx *c, int n_cells, const double *alpha,
         return alpha[a] < alpha[b];
     });
     for (int k = 0, lo = 0, hi = n_cells - 1; k < n_cells; k++) cells[k] = ((k & 3) == 3) ? sorted[hi--] : sorted[lo++];
-    std::vector<int> order(n_units);
-    for (int k = 0; k < n_cells; k++) for (int f = 0; f < nF; f++) order[k * nF + f] = cells[k] * nF + f;
+    D.order.resize(n_units);
+    for (int k = 0; k < n_cells; k++) for (int f = 0; f < nF; f++) D.order[k * nF + f] = cells[k] * nF + f;
 
     int occ = 1;
     const bool binom = c->prior == PAREBEN_PRIOR_BINOMIAL;
@@ -983,92 +1012,106 @@ extern "C" int pareben_ctx_run(pareben_ctx *c, int n_cells, const double *alpha,
     if (c->lazy && blocks > c->max_blocks) blocks = c->max_blocks;
     int rc = ensure_workspace(c, blocks);
     if (rc) return rc;
+    D.n_units = n_units; D.blocks = blocks;
 
-    double *d_alpha = nullptr, *d_lambda = nullptr, *d_err = nullptr;
-    int *d_order = nullptr, *d_queue = nullptr, *d_status = nullptr;
-    long long *d_cnt = nullptr, *d_phase = nullptr;
-    FsJob *d_jobs = nullptr; int *d_active = nullptr;
-    int act_host[4] = {0, 0, 0, 0};                             // lives until the stream is synchronised below
     const char *phase_path = getenv("PAREBEN_PHASE_DUMP");     // diagnostic build only
-    auto cleanup = [&]() { hipFree(d_jobs); hipFree(d_active); hipFree(d_phase); hipFree(d_alpha); hipFree(d_lambda); hipFree(d_err); hipFree(d_order); hipFree(d_queue); hipFree(d_status); hipFree(d_cnt); };
-#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(PAREBEN_EHIP, #x, e_); } } while (0)
-    CK(dmalloc(&d_alpha, (size_t)n_cells)); CK(dmalloc(&d_lambda, (size_t)n_cells));
-    CK(dmalloc(&d_err, (size_t)n_units)); CK(dmalloc(&d_order, (size_t)n_units));
-    CK(dmalloc(&d_queue, (size_t)1)); CK(dmalloc(&d_status, (size_t)n_units));
-    if (counters) CK(dmalloc(&d_cnt, (size_t)n_units * PAREBEN_NCOUNTERS));
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { D.release(); return fail(PAREBEN_EHIP, #x, e_); } } while (0)
+    CK(dmalloc(&D.d_alpha, (size_t)n_cells)); CK(dmalloc(&D.d_lambda, (size_t)n_cells));
+    CK(dmalloc(&D.d_err, (size_t)n_units)); CK(dmalloc(&D.d_order, (size_t)n_units));
+    CK(dmalloc(&D.d_queue, (size_t)1)); CK(dmalloc(&D.d_status, (size_t)n_units));
+    if (want_counters) CK(dmalloc(&D.d_cnt, (size_t)n_units * PAREBEN_NCOUNTERS));
 #ifdef PAREBEN_PHASE_TIMERS
-    if (phase_path) { CK(dmalloc(&d_phase, (size_t)n_units * PH_N)); CK(hipMemsetAsync(d_phase, 0, sizeof(long long) * (size_t)n_units * PH_N, c->stream)); }
+    if (phase_path) { CK(dmalloc(&D.d_phase, (size_t)n_units * PH_N)); CK(hipMemsetAsync(D.d_phase, 0, sizeof(long long) * (size_t)n_units * PH_N, c->stream)); }
 #else
     (void)phase_path;
 #endif
-    CK(hipMemcpyAsync(d_alpha, alpha, sizeof(double) * n_cells, hipMemcpyHostToDevice, c->stream));
-    CK(hipMemcpyAsync(d_lambda, lambda, sizeof(double) * n_cells, hipMemcpyHostToDevice, c->stream));
-    CK(hipMemcpyAsync(d_order, order.data(), sizeof(int) * n_units, hipMemcpyHostToDevice, c->stream));
-    CK(hipMemsetAsync(d_queue, 0, sizeof(int), c->stream));
+    CK(hipMemcpyAsync(D.d_alpha, alpha, sizeof(double) * n_cells, hipMemcpyHostToDevice, c->stream));
+    CK(hipMemcpyAsync(D.d_lambda, lambda, sizeof(double) * n_cells, hipMemcpyHostToDevice, c->stream));
+    CK(hipMemcpyAsync(D.d_order, D.order.data(), sizeof(int) * n_units, hipMemcpyHostToDevice, c->stream));
+    CK(hipMemsetAsync(D.d_queue, 0, sizeof(int), c->stream));
     // PAREBEN_SHARE (A/B tests): 0 = no shared phases, 1 = in the tail only, 2 = from the start; unset = automatic
     const char *share_env = getenv("PAREBEN_SHARE");
     const int share_mode = share_env ? atoi(share_env) : -1;
     if (!binom && share_mode != 0) {
-        CK(dmalloc(&d_jobs, (size_t)blocks)); CK(dmalloc(&d_active, (size_t)4));
-        CK(hipMemsetAsync(d_jobs, 0, sizeof(FsJob) * (size_t)blocks, c->stream));
-        act_host[0] = 0;                                        // workgroups that currently own a fit
-        CK(hipMemcpyAsync(d_active, act_host, sizeof act_host, hipMemcpyHostToDevice, c->stream));
+        CK(dmalloc(&D.d_jobs, (size_t)blocks)); CK(dmalloc(&D.d_active, (size_t)4));
+        CK(hipMemsetAsync(D.d_jobs, 0, sizeof(FsJob) * (size_t)blocks, c->stream));
+        D.act_host[0] = 0;                                      // workgroups that currently own a fit
+        CK(hipMemcpyAsync(D.d_active, D.act_host, sizeof D.act_host, hipMemcpyHostToDevice, c->stream));
     }
-    CK(hipMemsetAsync(d_err, 0xFF, sizeof(double) * n_units, c->stream));       // NaN-poison
-    CK(hipMemsetAsync(d_status, 0xFF, sizeof(int) * n_units, c->stream));
+    CK(hipMemsetAsync(D.d_err, 0xFF, sizeof(double) * n_units, c->stream));       // NaN-poison
+    CK(hipMemsetAsync(D.d_status, 0xFF, sizeof(int) * n_units, c->stream));
 
     CK(hipEventRecord(c->ev[0], c->stream));
     rc = prepare_folds(c);
-    if (rc) { cleanup(); return rc; }
+    if (rc) { D.release(); return rc; }
     CK(hipEventRecord(c->ev[1], c->stream));
 
     CvParams P;
-    P.folds = c->d_folds; P.alpha = d_alpha; P.lambda = d_lambda; P.order = d_order; P.queue = d_queue;
-    P.fold_err = d_err; P.status = d_status; P.counters = d_cnt; P.phase = d_phase; P.ws = c->d_ws;
+    P.folds = c->d_folds; P.alpha = D.d_alpha; P.lambda = D.d_lambda; P.order = D.d_order; P.queue = D.d_queue;
+    P.fold_err = D.d_err; P.status = D.d_status; P.counters = D.d_cnt; P.phase = D.d_phase; P.ws = c->d_ws;
     P.ws_stride = c->L.bytes; P.offK = c->L.offK; P.offSig = c->L.offSig; P.offM = c->L.offM;
     P.K = c->kfull; P.cap = c->cap; P.cap_flag = c->cap_ref; P.n_folds = nF; P.n_units = n_units; P.v = c->variant;
     P.priv_rows = c->priv_rows; P.priv_base0 = nF * c->pool_rows;
-    P.jobs = d_jobs; P.active = d_active;
+    P.jobs = D.d_jobs; P.active = D.d_active;
     // with only a handful of fits per workgroup the longest fits decide the step time: share from the start
     // (measured on config-2 shares with 256 workgroups: 1250 fits 2.51 -> 2.27 s, 2500 fits 3.82 -> 3.55 s, 5000 fits 6.15 -> 6.37 s)
-    P.early = (d_jobs && (share_mode == 2 || (share_mode < 0 && n_units <= 10 * blocks))) ? 1 : 0;
+    P.early = (D.d_jobs && (share_mode == 2 || (share_mode < 0 && n_units <= 10 * blocks))) ? 1 : 0;
     { const char *hm = getenv("PAREBEN_HEAVY_M"); P.heavy_m = share_mode == 1 ? (1 << 30) : (hm ? atoi(hm) : 384); }
     if (binom) {
         BmCvParams Q;
-        Q.folds = c->d_folds; Q.alpha = d_alpha; Q.lambda = d_lambda; Q.order = d_order; Q.queue = d_queue;
-        Q.fold_err = d_err; Q.status = d_status; Q.counters = d_cnt; Q.ws = c->d_ws; Q.L = c->BL;
-        Q.K = c->p; Q.n_folds = nF; Q.n_units = n_units; Q.phase = d_phase;
+        Q.folds = c->d_folds; Q.alpha = D.d_alpha; Q.lambda = D.d_lambda; Q.order = D.d_order; Q.queue = D.d_queue;
+        Q.fold_err = D.d_err; Q.status = D.d_status; Q.counters = D.d_cnt; Q.ws = c->d_ws; Q.L = c->BL;
+        Q.K = c->p; Q.n_folds = nF; Q.n_units = n_units; Q.phase = D.d_phase;
         hipLaunchKernelGGL(bm_cv_kernel, dim3(blocks), dim3(FIT_THREADS), LDS_FIT_BYTES, c->stream, Q);
     } else {
         hipLaunchKernelGGL(gm_cv_kernel, dim3(blocks), dim3(FIT_THREADS), LDS_FIT_BYTES, c->stream, P);
     }
     CK(hipGetLastError());
     CK(hipEventRecord(c->ev[2], c->stream));
-
-    CK(hipMemcpyAsync(fold_err, d_err, sizeof(double) * n_units, hipMemcpyDeviceToHost, c->stream));
-    std::vector<int> st(n_units);
-    CK(hipMemcpyAsync(st.data(), d_status, sizeof(int) * n_units, hipMemcpyDeviceToHost, c->stream));
-    if (counters) CK(hipMemcpyAsync(counters, d_cnt, sizeof(int64_t) * (size_t)n_units * PAREBEN_NCOUNTERS, hipMemcpyDeviceToHost, c->stream));
-    CK(hipEventRecord(c->ev[3], c->stream));
-    CK(hipStreamSynchronize(c->stream));
-    if (status) for (int i = 0; i < n_units; i++) status[i] = st[i];
-    if (d_phase) {
-        std::vector<long long> ph((size_t)n_units * PH_N);
-        CK(hipMemcpy(ph.data(), d_phase, sizeof(long long) * ph.size(), hipMemcpyDeviceToHost));
-        if (FILE *fp = fopen(phase_path, "wb")) { fwrite(ph.data(), sizeof(long long), ph.size(), fp); fclose(fp); }
-    }
-    float a = 0, b = 0, t = 0;
-    CK(hipEventElapsedTime(&a, c->ev[0], c->ev[1]));
-    CK(hipEventElapsedTime(&b, c->ev[1], c->ev[2]));
-    CK(hipEventElapsedTime(&t, c->ev[0], c->ev[3]));
-    c->last_ms[0] = a; c->last_ms[1] = b; c->last_ms[2] = t;
+#undef CK
     c->launch_info[0] = blocks; c->launch_info[1] = FIT_THREADS;
     c->launch_info[2] = binom ? c->BL.cap : c->cap;
     c->launch_info[4] = binom ? c->BL.cap : c->cap_ref;
     c->launch_info[3] = (int64_t)((binom ? c->BL.bytes : c->L.bytes) >> 10);
-#undef CK
-    cleanup();
     return PAREBEN_OK;
+}
+
+// after the stream has been synchronised: event timings of the launch into the context
+static int run_timings(pareben_ctx *c)
+{
+    float a = 0, b = 0, t = 0;
+    HIPCHK(hipEventElapsedTime(&a, c->ev[0], c->ev[1]));
+    HIPCHK(hipEventElapsedTime(&b, c->ev[1], c->ev[2]));
+    HIPCHK(hipEventElapsedTime(&t, c->ev[0], c->ev[3]));
+    c->last_ms[0] = a; c->last_ms[1] = b; c->last_ms[2] = t;
+    return PAREBEN_OK;
+}
+
+extern "C" int pareben_ctx_run(pareben_ctx *c, int n_cells, const double *alpha, const double *lambda,
+                               double *fold_err, int32_t *status, int64_t *counters)
+{
+    if (!c || n_cells < 1 || !alpha || !lambda || !fold_err) return fail(PAREBEN_EINVAL, "bad argument");
+    RunDev D;
+    int rc = run_enqueue(c, n_cells, alpha, lambda, counters != nullptr, D);
+    if (rc) return rc;
+    const int n_units = D.n_units;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { D.release(); return fail(PAREBEN_EHIP, #x, e_); } } while (0)
+    CK(hipMemcpyAsync(fold_err, D.d_err, sizeof(double) * n_units, hipMemcpyDeviceToHost, c->stream));
+    std::vector<int> st(n_units);
+    CK(hipMemcpyAsync(st.data(), D.d_status, sizeof(int) * n_units, hipMemcpyDeviceToHost, c->stream));
+    if (counters) CK(hipMemcpyAsync(counters, D.d_cnt, sizeof(int64_t) * (size_t)n_units * PAREBEN_NCOUNTERS, hipMemcpyDeviceToHost, c->stream));
+    CK(hipEventRecord(c->ev[3], c->stream));
+    CK(hipStreamSynchronize(c->stream));
+    if (status) for (int i = 0; i < n_units; i++) status[i] = st[i];
+    if (D.d_phase) {
+        std::vector<long long> ph((size_t)n_units * PH_N);
+        CK(hipMemcpy(ph.data(), D.d_phase, sizeof(long long) * ph.size(), hipMemcpyDeviceToHost));
+        if (FILE *fp = fopen(getenv("PAREBEN_PHASE_DUMP"), "wb")) { fwrite(ph.data(), sizeof(long long), ph.size(), fp); fclose(fp); }
+    }
+#undef CK
+    rc = run_timings(c);
+    D.release();
+    return rc;
 }
 
 extern "C" int pareben_ctx_gram(pareben_ctx *c, int fold, double *out)
@@ -1113,6 +1156,158 @@ extern "C" int pareben_cv_grid(const double *basis, int n, int p, const double *
     rc = pareben_ctx_run(c, n_cells, alpha, lambda, fold_err, status, counters);
     pareben_ctx_destroy(c);
     return rc;
+}
+
+// ------------------------------------------------------------------------------------------
+// Multi-GPU grid evaluation behind the C ABI: ONE host process (the caller is a single R
+// session), one host thread + context per device, cells dealt round-robin over the cost-sorted list, and the
+// path's only exchange -- one grouped ncclAllGather (RCCL over xGMI) of the device-resident per-cell results,
+// after which every GPU holds the whole table and the host reads it from the first.
+// RCCL is bound at run time (dlopen), so the library loads and the single-GPU entries work without it.
+struct Rccl {
+    void *h = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+static int rccl_load(Rccl &R)
+{
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names) { R.h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (R.h) break; }
+    if (!R.h) return fail(PAREBEN_EUNSUPPORTED, "RCCL (librccl.so) not found: the multi-GPU entry needs it");
+    R.CommInitAll = (decltype(R.CommInitAll))dlsym(R.h, "ncclCommInitAll");
+    R.CommDestroy = (decltype(R.CommDestroy))dlsym(R.h, "ncclCommDestroy");
+    R.GroupStart = (decltype(R.GroupStart))dlsym(R.h, "ncclGroupStart");
+    R.GroupEnd = (decltype(R.GroupEnd))dlsym(R.h, "ncclGroupEnd");
+    R.AllGather = (decltype(R.AllGather))dlsym(R.h, "ncclAllGather");
+    R.GetErrorString = (decltype(R.GetErrorString))dlsym(R.h, "ncclGetErrorString");
+    if (!R.CommInitAll || !R.CommDestroy || !R.GroupStart || !R.GroupEnd || !R.AllGather || !R.GetErrorString)
+        return fail(PAREBEN_EUNSUPPORTED, "librccl.so lacks an expected symbol");
+    return PAREBEN_OK;
+}
+
+// one row per cell of the rank's shard: (global cell id, n_folds scores, n_folds status words as doubles);
+// rows past the shard carry id -1
+__global__ void pack_kernel(const double *__restrict__ ids, const double *__restrict__ err, const int *__restrict__ st,
+                            int n_mine, int per, int nF, double *__restrict__ out)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= per) return;
+    double *row = out + (size_t)c * (2 * nF + 1);
+    if (c < n_mine) {
+        row[0] = ids[c];
+        for (int f = 0; f < nF; f++) { row[1 + f] = err[(size_t)c * nF + f]; row[1 + nF + f] = (double)st[(size_t)c * nF + f]; }
+    } else {
+        row[0] = -1.0;
+        for (int f = 0; f < 2 * nF; f++) row[1 + f] = 0.0;
+    }
+}
+
+extern "C" int pareben_cv_grid_multi(const double *basis, int n, int p, const double *target,
+                                     const int32_t *fold_id, int n_folds,
+                                     const double *alpha, const double *lambda, int n_cells,
+                                     int epis, int prior, int n_gpu,
+                                     double *fold_err, int32_t *status, int64_t *counters)
+{
+    if (!basis || !target || !fold_id || !alpha || !lambda || !fold_err || n_cells < 1 || n_folds < 1) return fail(PAREBEN_EINVAL, "bad argument");
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (n_gpu <= 0) n_gpu = ndev;
+    if (n_gpu < 1 || n_gpu > ndev) return fail(PAREBEN_EINVAL, "n_gpu exceeds the visible devices");
+    if (n_gpu > n_cells) n_gpu = n_cells;
+    const int nF = n_folds, row = 2 * nF + 1;
+    const int per = (n_cells + n_gpu - 1) / n_gpu;
+    // shard: cost-sorted (small lambda first, then alpha), dealt round-robin -- the same split as pareben_amd.dist.shard_cells
+    std::vector<int> order(n_cells);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        if (lambda[a] != lambda[b]) return lambda[a] < lambda[b];
+        return alpha[a] < alpha[b];
+    });
+    struct Rank {
+        pareben_ctx *ctx = nullptr; RunDev D; std::vector<int> cells; std::vector<double> a, l, ids;
+        double *d_ids = nullptr, *d_send = nullptr, *d_recv = nullptr; int rc = 0; std::string err;
+    };
+    std::vector<Rank> R(n_gpu);
+    for (int k = 0; k < n_cells; k++) R[k % n_gpu].cells.push_back(order[k]);
+    auto work = [&](int g) {
+        Rank &r = R[g];
+        auto bail = [&](int code) { r.rc = code; r.err = pareben_last_error(); };
+        const int nm = (int)r.cells.size();
+        r.a.resize(nm); r.l.resize(nm); r.ids.resize(nm);
+        for (int k = 0; k < nm; k++) { r.a[k] = alpha[r.cells[k]]; r.l[k] = lambda[r.cells[k]]; r.ids[k] = (double)r.cells[k]; }
+        int rc = pareben_ctx_create(&r.ctx, g, basis, n, p, target, fold_id, n_folds, prior, epis, 0);
+        if (rc) return bail(rc);
+        rc = run_enqueue(r.ctx, nm, r.a.data(), r.l.data(), counters != nullptr, r.D);
+        if (rc) return bail(rc);
+        hipStream_t s = r.ctx->stream;
+        if (dmalloc(&r.d_ids, (size_t)nm) != hipSuccess || dmalloc(&r.d_send, (size_t)per * row) != hipSuccess ||
+            dmalloc(&r.d_recv, (size_t)n_gpu * per * row) != hipSuccess) return bail(fail(PAREBEN_ENOMEM, "gather buffers"));
+        if (hipMemcpyAsync(r.d_ids, r.ids.data(), sizeof(double) * nm, hipMemcpyHostToDevice, s) != hipSuccess) return bail(fail(PAREBEN_EHIP, "ids upload"));
+        hipLaunchKernelGGL(pack_kernel, dim3((per + 127) / 128), dim3(128), 0, s, r.d_ids, r.D.d_err, r.D.d_status, nm, per, nF, r.d_send);
+        if (counters) {                                          // diagnostics only: straight to the host table, not part of the exchange
+            std::vector<int64_t> cl((size_t)nm * nF * PAREBEN_NCOUNTERS);
+            if (hipMemcpyAsync(cl.data(), r.D.d_cnt, sizeof(int64_t) * cl.size(), hipMemcpyDeviceToHost, s) != hipSuccess ||
+                hipStreamSynchronize(s) != hipSuccess) return bail(fail(PAREBEN_EHIP, "counter copy"));
+            for (int k = 0; k < nm; k++)
+                memcpy(counters + (size_t)r.cells[k] * nF * PAREBEN_NCOUNTERS, cl.data() + (size_t)k * nF * PAREBEN_NCOUNTERS, sizeof(int64_t) * nF * PAREBEN_NCOUNTERS);
+        }
+        if (hipEventRecord(r.ctx->ev[3], s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return bail(fail(PAREBEN_EHIP, "fit launch", hipGetLastError()));
+        run_timings(r.ctx);
+    };
+    std::vector<std::thread> th;
+    for (int g = 0; g < n_gpu; g++) th.emplace_back(work, g);
+    // communicators come up while the GPUs fit
+    Rccl X;
+    std::vector<ncclComm_t> comms(n_gpu, nullptr);
+    std::vector<int> devs(n_gpu);
+    std::iota(devs.begin(), devs.end(), 0);
+    int rc = rccl_load(X);
+    ncclResult_t nr = ncclSuccess;
+    if (!rc) nr = X.CommInitAll(comms.data(), n_gpu, devs.data());
+    for (auto &t : th) t.join();
+    auto cleanup = [&]() {
+        for (int g = 0; g < n_gpu; g++) {
+            if (R[g].ctx) hipSetDevice(g);
+            hipFree(R[g].d_ids); hipFree(R[g].d_send); hipFree(R[g].d_recv);
+            R[g].D.release();
+            if (comms[g]) X.CommDestroy(comms[g]);
+            if (R[g].ctx) pareben_ctx_destroy(R[g].ctx);
+        }
+    };
+    if (rc) { cleanup(); return rc; }
+    if (nr != ncclSuccess) { std::string m = std::string("ncclCommInitAll: ") + X.GetErrorString(nr); cleanup(); return fail(PAREBEN_EHIP, m.c_str()); }
+    for (int g = 0; g < n_gpu; g++) if (R[g].rc) { const int code = R[g].rc; const std::string m = R[g].err; cleanup(); return fail(code, m.c_str()); }
+    // the path's one collective: every rank contributes its packed slice, every GPU ends with the whole table
+    nr = X.GroupStart();
+    for (int g = 0; g < n_gpu && nr == ncclSuccess; g++)
+        nr = X.AllGather(R[g].d_send, R[g].d_recv, (size_t)per * row, ncclDouble, comms[g], R[g].ctx->stream);
+    { const ncclResult_t ne = X.GroupEnd(); if (nr == ncclSuccess) nr = ne; }
+    if (nr != ncclSuccess) { std::string m = std::string("ncclAllGather: ") + X.GetErrorString(nr); cleanup(); return fail(PAREBEN_EHIP, m.c_str()); }
+    for (int g = 0; g < n_gpu; g++) {
+        hipSetDevice(g);
+        if (hipStreamSynchronize(R[g].ctx->stream) != hipSuccess) { cleanup(); return fail(PAREBEN_EHIP, "all-gather", hipGetLastError()); }
+    }
+    std::vector<double> tab((size_t)n_gpu * per * row);
+    hipSetDevice(0);
+    if (hipMemcpy(tab.data(), R[0].d_recv, sizeof(double) * tab.size(), hipMemcpyDeviceToHost) != hipSuccess) { cleanup(); return fail(PAREBEN_EHIP, "table copy", hipGetLastError()); }
+    int seen = 0;
+    for (size_t k = 0; k < (size_t)n_gpu * per; k++) {
+        const double *rw = tab.data() + k * row;
+        if (rw[0] < 0) continue;
+        const int cell = (int)rw[0];
+        for (int f = 0; f < nF; f++) {
+            fold_err[(size_t)cell * nF + f] = rw[1 + f];
+            if (status) status[(size_t)cell * nF + f] = (int32_t)rw[1 + nF + f];
+        }
+        seen++;
+    }
+    cleanup();
+    if (seen != n_cells) return fail(PAREBEN_EHIP, "all-gather returned an incomplete table");
+    return PAREBEN_OK;
 }
 
 // one fit on all rows: a pseudo-fold whose training set is every row and whose held-out set is empty

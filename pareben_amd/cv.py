@@ -22,7 +22,7 @@ def _frame(cols):
 
 
 def CrossValidate(BASIS, Target, nFolds, foldId=0, Epis="no", prior="gaussian", search="global",
-                  nAlpha=20, nLambda=20, device=0, sample_kind="Rejection", rank=0, world_size=1,
+                  nAlpha=20, nLambda=20, nGPU=1, device=0, sample_kind="Rejection", rank=0, world_size=1,
                   gather=None, return_stats=False):
     """Hyper-parameter sweep + cross-validation of the empirical Bayesian elastic net.
 
@@ -31,9 +31,10 @@ def CrossValidate(BASIS, Target, nFolds, foldId=0, Epis="no", prior="gaussian", 
     ``foldId`` argument is accepted and ignored there (R/TestModel.R:9) -- here a
     full-length ``foldId`` is honoured, anything else falls back to ``AssignToFolds``.
 
-    Extensions (trailing, optional): nAlpha/nLambda grid sizes (reference: fixed 20 x 20),
-    device, sample_kind (R's sampler generation for the folds), and rank/world_size/gather for the
-    one-process-per-GPU split of the grid (see pareben_amd.dist).
+    Extensions (trailing, optional): nAlpha/nLambda grid sizes (reference: fixed 20 x 20); nGPU: devices this ONE
+    process spreads the grid over through the C ABI (pareben_cv_grid_multi: a host thread per device and one RCCL
+    all-gather; 0 = all visible; the R drop-in's route); device, sample_kind (R's sampler generation for the folds);
+    and rank/world_size/gather for the one-process-per-GPU split (pareben_amd.dist, what bench.py / torchrun use).
     """
     if search != "global":                  # R/CrossValidate.R:112-115
         from .local import LocalSearch
@@ -50,10 +51,13 @@ def CrossValidate(BASIS, Target, nFolds, foldId=0, Epis="no", prior="gaussian", 
     order = np.lexsort((alpha, lam))
     mine = order[rank::world_size] if world_size > 1 else np.arange(n_cells)
     stats = {}
-    with _lib.Context(X, y, folds, nFolds, prior=prior, epis=(Epis == "yes"), device=device) as ctx:
-        err_local, st_local, cnt_local = ctx.run(alpha[mine], lam[mine])
-        stats["timing"] = ctx.last_timing()
-        stats["launch"] = ctx.launch_info()
+    if nGPU != 1 and world_size == 1:
+        err_local, st_local, cnt_local = _lib.cv_grid_multi(X, y, folds, nFolds, alpha, lam, prior=prior, epis=(Epis == "yes"), n_gpu=nGPU)
+    else:
+        with _lib.Context(X, y, folds, nFolds, prior=prior, epis=(Epis == "yes"), device=device) as ctx:
+            err_local, st_local, cnt_local = ctx.run(alpha[mine], lam[mine])
+            stats["timing"] = ctx.last_timing()
+            stats["launch"] = ctx.launch_info()
     if world_size > 1:
         if gather is None:
             raise ValueError("world_size > 1 needs a gather callable (see pareben_amd.dist.all_gather_cells)")

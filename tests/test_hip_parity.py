@@ -463,3 +463,66 @@ def test_config2_cells_vs_oracle_fixture():
     tot = cnt.sum(axis=(0, 1))
     for j, n in enumerate(("n_outer", "n_inner", "n_add", "n_del", "n_reest", "n_fullstat")):
         assert tot[j] == want[n], n
+
+
+def test_multi_gpu_entry_through_rccl(golden):
+    """pareben_cv_grid_multi (one process, a host thread + context per device, ncclCommInitAll + one grouped
+    ncclAllGather of the device-resident results) on the devices this box has: the table that comes back through
+    RCCL is bit-identical to the single-context run, for Gaussian and binomial grids, with n_gpu given and defaulted."""
+    X, y = golden.BASIS[:120, :90], golden.y[:120]
+    fid = AssignToFolds(X, 3)
+    alpha, lam = BuildGrid(X, y, 3)
+    sel = np.arange(0, 400, 3)
+    with pareben_amd.Context(X, y, fid, 3) as ctx:
+        E1, s1, c1 = ctx.run(alpha[sel], lam[sel])
+    n_dev = pareben_amd.load_library().pareben_device_count()
+    for n_gpu in sorted({1, 0, min(n_dev, 2)}):
+        E2, s2, c2 = pareben_amd.cv_grid_multi(X, y, fid, 3, alpha[sel], lam[sel], n_gpu=n_gpu)
+        assert np.array_equal(E1, E2) and np.array_equal(s1, s2) and np.array_equal(c1, c2), n_gpu
+    out = pareben_amd.CrossValidate(X, y, nFolds=3, nGPU=0)
+    ref = pareben_amd.CrossValidate(X, y, nFolds=3)
+    assert out["lambda.optimal"] == ref["lambda.optimal"] and out["alpha.optimal"] == ref["alpha.optimal"]
+    assert np.array_equal(np.asarray(out["Results.Detail"]["MSE"]), np.asarray(ref["Results.Detail"]["MSE"]))
+    Xb, yb = golden.BASISbinomial[::2, :80], golden.yBinomial[::2]      # both classes present
+    fb = AssignToFolds(Xb, 2)
+    ab, lb = BuildGrid(Xb, yb, 2)
+    with pareben_amd.Context(Xb, yb, fb, 2, prior="binomial") as ctx:
+        E3, s3, _ = ctx.run(ab[::7], lb[::7])
+    E4, s4, _ = pareben_amd.cv_grid_multi(Xb, yb, fb, 2, ab[::7], lb[::7], prior="binomial", n_gpu=1)
+    assert np.array_equal(E3, E4) and np.array_equal(s3, s4)
+    with pytest.raises(pareben_amd.ParebenError):
+        pareben_amd.cv_grid_multi(X, y, fid, 3, alpha[sel], lam[sel], n_gpu=n_dev + 1)
+
+
+def test_config5_full_size_properties():
+    """BASELINE config 5 at its stated size (synthetic n = 2000, p = 50000, nFolds = 10, 20 alpha x 200 lambda;
+    ten 20 GB Gram matrices resident in HBM), on twelve cells spread over the lambda range (120 fits; the whole
+    grid is `bench.py --workload config5`, 40 000 fits, profiles/r02/).  The oracle cannot follow at this size, so
+    size-independent properties: every score finite (the reference's basisMax = 1e7/p = 200 only flags a fit
+    here; the workspace holds 1024 columns), null-model bound at the largest lambda, informative cells beat the
+    null model, target-shift invariance, bit-identical rerun in another order."""
+    from pareben_amd.synth import synthetic_gaussian as bench_design
+    n, p, nf = 2000, 50000, 10
+    X, y, _, _ = bench_design(n, p)
+    fid = AssignToFolds(X, nf)
+    alpha, lam = BuildGrid(X, y, nf, nAlpha=20, nLambda=200)
+    A = alpha.reshape(200, 20); L = lam.reshape(200, 20)             # [lambda index, alpha index], alpha fastest
+    li = np.array([0, 40, 80, 100, 120, 160]); ai = np.array([0, 10])
+    sel = (li[:, None] * 20 + ai[None, :]).ravel()
+    assert np.all(A.ravel()[sel].reshape(6, 2)[:, 0] == 1.0)
+    with pareben_amd.Context(X, y, fid, nf) as ctx:
+        E, st, cnt = ctx.run(alpha[sel], lam[sel])
+        info = ctx.launch_info()
+        perm = np.random.default_rng(5).permutation(len(sel))
+        E2, st2, _ = ctx.run(alpha[sel][perm], lam[sel][perm])
+    assert info["reference_capacity"] == 200 and info["capacity"] == 1024
+    assert np.all((st & 8) == 0) and np.all(np.isfinite(E)) and np.all(E > 0)
+    assert ((st & 1) != 0).sum() > 0 and cnt[..., 10].max() > 200       # fits the reference would have run off its arrays with
+    assert np.array_equal(E2, E[perm]) and np.array_equal(st2, st[perm])
+    null = np.array([np.sum((y[fid == f + 1] - y[fid != f + 1].mean()) ** 2) for f in range(nf)])
+    assert np.all(E < 1.01 * null[None, :])                          # no cell does worse than the intercept-only model
+    assert E.mean(axis=1).min() < 0.1 * null.mean()                  # 20 strong causal columns: the good cells explain > 90 %
+    spot = [0, 4, 9]
+    with pareben_amd.Context(X, y + 3.0, fid, nf) as ctx:
+        Es, _, _ = ctx.run(alpha[sel][spot], lam[sel][spot])
+    assert _rel(Es, E[spot]).max() < 1e-6

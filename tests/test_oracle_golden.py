@@ -115,3 +115,31 @@ def test_oracle_epistasis_known_answers(golden, oracle):
     assert len(nz) >= 1 and np.array_equal(B[nz, 4], nz + 1)
     pairs = nz[nz >= 60]
     assert np.all(B[pairs, 0] < B[pairs, 1])
+
+
+@pytest.mark.slow
+def test_oracle_reproduces_real_r_fit(golden, yeast):
+    """The oracle's pin to the reference itself: one fit of the authors' stored real-R run
+    (paper_materials/Real Data Analysis/10000_Features/LooserSubset_10000_ParCV_5-3-2018.RDS, R 3.5.0 + CRAN EBEN
+    with R's reference BLAS) recomputed with the oracle on the same inputs -- yeast 3803 x 10000, R<3.6 fold sampler,
+    cell 21 (alpha = 0.95, lambda = 2.1946), held-out fold 2: 2535 training rows, 490 inner iterations, active set up
+    to 393, 44 features kept.  Results.Detail$MSE of that row must come out to the last digits (observed 6e-16).
+    ~100 s of one core: the shortest non-trivial fit of the table; nothing else in the reference tree holds a fit
+    output for this path.  If oracle/eben_gm.c drifts from the reference's algorithm, this fails."""
+    import oracle_lib as O
+    from pareben_amd.grid import AssignToFolds
+    G, y = yeast
+    r = golden.rds
+    cell, fold = 21, 2
+    row = cell * 3 + (fold - 1)
+    al, lm, want = float(r["detail_alpha"][row]), float(r["detail_lambda"][row]), float(r["detail_MSE"][row])
+    assert int(r["detail_foldId"][row]) == fold
+    fid = AssignToFolds(G, 3, sample_kind="Rounding")
+    tr, te = fid != fold, fid == fold
+    o = O.fit_gaussian(np.asfortranarray(G[tr]), y[tr], lm, al)
+    assert o["rc"] == 0 and o["counters"]["status"] == 0
+    nz = np.nonzero(o["Beta"][:, 2])[0]
+    pred = o["intercept"] + G[te][:, nz] @ o["Beta"][nz, 2]           # R/GetModelError.R:7-32
+    sse = float(np.sum((y[te] - pred) ** 2))
+    assert abs(sse - want) <= 1e-12 * want, (sse, want)
+    assert o["counters"]["m_final"] == len(nz) == 44 and o["counters"]["m_max"] == 393 and o["counters"]["n_inner"] == 490

@@ -39,3 +39,50 @@ def test_cells_match_real_r(golden, yeast):
     assert np.all(st & 8 == 0)
     rel = np.abs(E - want) / want
     assert rel.max() < 1e-9, (rel, E, want)          # north-star bar is 1e-6; observed 1e-15 ... 5e-13
+
+
+def test_full_table_vs_real_r(golden, yeast):
+    """All 1200 fits of the authors' stored run (400 cells x 3 folds, ~50 s on one MI355X) against
+    Results.Detail$MSE, Results.Summary and (lambda.optimal, alpha.optimal).
+
+    Bar: fold SSE within 1e-9 (relative) of real R -- except for the (cell, fold) pairs listed in
+    tests/golden/yeast_table_deviations.json.  Those are long add/delete trajectories (alpha = 1, transient active
+    sets of several hundred, thousands of inner iterations) on which a last-bit difference in one dML flips a
+    discrete decision; the reference itself leaves its trajectory there when its BLAS sums in another order
+    (DESIGN.md, "Parity on chaotic fits"; tests/test_oracle_golden.py::test_oracle_reproduces_real_r_fit pins the
+    netlib-order oracle to real R on such data).  The list is part of the contract: a pair that is not listed must
+    meet the bar, a listed pair must give the recorded value (the kernel is deterministic), and the summary-level
+    consequences are bounded by what the fixture records.  Regenerate with
+    `python tools/yeast_full_table.py 400 profiles/r02/yeast_full_table_vs_real_R.json tests/golden/yeast_table_deviations.json`
+    after any change of summation order in the fit kernel."""
+    import json, os
+    G, y = yeast
+    r = golden.rds
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "yeast_table_deviations.json")))
+    fid = AssignToFolds(G, 3, sample_kind="Rounding")
+    alpha = r["detail_alpha"][::3]; lam = r["detail_lambda"][::3]
+    want = r["detail_MSE"].reshape(400, 3)
+    with pareben_amd.Context(G, y, fid, 3) as ctx:
+        E, st, cnt = ctx.run(alpha, lam)
+    assert np.all(st & 8 == 0)
+    rel = np.abs(E - want) / want
+    listed = np.zeros((400, 3), dtype=bool)
+    for p in fx["pairs"]:
+        listed[p["cell"], p["fold"] - 1] = True
+        assert abs(E[p["cell"], p["fold"] - 1] - p["gpu"]) <= 1e-12 * abs(p["gpu"]), p     # the recorded value of this build
+    assert len(fx["pairs"]) <= 24                                       # 2 % of the table at most
+    assert rel[~listed].max() < 1e-9, np.argwhere((rel >= 1e-9) & ~listed)
+    assert rel.max() < 1e-2
+    # (alpha*, lambda*) exact, cv.error at the optimum within the north-star 1e-6
+    a_s, l_s, se, cv, idx = summarise_cv(alpha, lam, E, 3)
+    assert a_s[idx] == r["alpha_optimal"][0] and l_s[idx] == r["lambda_optimal"][0]
+    assert abs(cv[idx] - r["summary_MSE"][idx]) <= 1e-6 * r["summary_MSE"][idx]
+    # Results.Summary: rows without a listed fit agree to 1e-9 (MSE) / 1e-6 (SE: a difference of nearly equal numbers);
+    # rows with one are bounded by the recorded deviations
+    order = np.lexsort((lam, alpha))
+    clean = ~listed.any(axis=1)[order]
+    d_mse = np.abs(cv - r["summary_MSE"]) / r["summary_MSE"]
+    d_se = np.abs(se - r["summary_SE"]) / r["summary_SE"]
+    assert np.array_equal(a_s, r["summary_alpha"]) and np.allclose(l_s, r["summary_lambda"], rtol=1e-13, atol=0)
+    assert d_mse[clean].max() < 1e-9 and d_se[clean].max() < 1e-6
+    assert d_mse.max() <= fx["max_rel_diff_summary_mse"] * 1.0001 + 1e-12 and d_se.max() <= fx["max_rel_diff_summary_se"] * 1.0001 + 1e-12

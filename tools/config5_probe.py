@@ -46,6 +46,10 @@ else:
     rep["best_cell"] = {"alpha": float(alpha[sel][best]), "lambda": float(lam[sel][best]), "cv_error": float(cv[best])}
 rep["flagged_past_basisMax"] = int(((st & 1) != 0).sum())
 rep["m_max_by_lambda_index"] = {int(l): int(cnt[..., 10].reshape(len(ai), len(li), nf)[:, j, :].max()) for j, l in enumerate(li)}
+ab = np.argwhere((st & 8) != 0)
+rep["stopped"] = [{"alpha": float(alpha[sel][c]), "lambda_index": int(np.searchsorted(-np.unique(lam)[::-1], -lam[sel][c])), "fold": int(f) + 1,
+                   "status": int(st[c, f]), "m_max": int(cnt[c, f, 10]), "m_final": int(cnt[c, f, 9]), "n_inner": int(cnt[c, f, 1]),
+                   "n_outer": int(cnt[c, f, 0])} for c, f in ab[:60]]
 print(json.dumps(rep), flush=True)
 if n_or > 0:
     import oracle_lib
