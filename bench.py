@@ -220,7 +220,7 @@ def main():
 
     # ---- the cold first call, from CrossValidate's entry: grid, folds, context (H2D + device buffers), first run
     t_entry = time.perf_counter()
-    alpha, lam = BuildGrid(X, y, nF, "yes" if epis else "no", nAlpha=n_alpha, nLambda=n_lambda)
+    alpha, lam = BuildGrid(X, y, nF, "yes" if epis else "no", nAlpha=n_alpha, nLambda=n_lambda, device=dev_index if world > 1 else 0)
     folds = AssignToFolds(X, nF)
     t_grid = time.perf_counter() - t_entry
     n_cells = len(alpha)

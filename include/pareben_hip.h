@@ -14,6 +14,8 @@
  *                                       :88-92, i.e. R/TestModel.R:6-39 (fold split, fit, score),
  *                                       EBEN_orig/R/EBelasticNet.Gaussian.R:39-66 (.C marshalling,
  *                                       non-zero-row filter) and R/GetModelError.R:6-59
+ *   pareben_lambda_max_pairs            the Epis = "yes" double loop of GetLambdaMax, R/BuildGrid.R:21-30
+ *   pareben_cv_grid_multi               the same foreach, its workers spread over the GPUs of one node
  *   pareben_fit_gaussian                .C("elasticNetLinearNeMainEff", ...) in
  *                                       EBEN_orig/R/EBelasticNet.Gaussian.R:39-51, i.e.
  *                                       EBEN_orig/src/elasticNetLinearNeMainEff.c:55
@@ -23,6 +25,9 @@
  *   pareben_fit_binomial                .C("ElasticNetBinaryNEmainEff", ...) in
  *                                       EBEN_orig/R/EBelasticNet.Binomial.R:32-46, i.e.
  *                                       EBEN_orig/src/ElasticNetBinaryNEmainEff.c:236
+ *   pareben_fit_binomial_epis           .C("ElasticNetBinaryNEfull", ...) in
+ *                                       EBEN_orig/R/EBelasticNet.Binomial.R:6-26, i.e.
+ *                                       EBEN_orig/src/ElasticNetBinaryNeFull.c:52
  */
 #ifndef PAREBEN_HIP_H
 #define PAREBEN_HIP_H
@@ -63,7 +68,8 @@ int pareben_device_count(void);
  * Stage one CV problem in HBM: BASIS (n x p, column-major), Target (n), fold ids (1..n_folds,
  * what R/AssignToFolds.R:6-19 returns).  prior: gaussian (elasticNetLinearNeMainEff.c /
  * elasticNetLinearNeFull2.c) or binomial (ElasticNetBinaryNEmainEff.c).  epis: 0 = main effects,
- * 1 = add the p(p-1)/2 pairwise columns x_i*x_j in the reference's order (gaussian only).
+ * 1 = add the p(p-1)/2 pairwise columns x_i*x_j in the reference's order (elasticNetLinearNeFull2.c /
+ * ElasticNetBinaryNeFull.c).
  * Active-set capacity.  The reference sizes its arrays for basisMax = min(p, 1e7/p) columns
  * (elasticNetLinearNeMainEff.c:68-69; elasticNetLinearNeFull2.c:67-80 with epistasis) and runs off them when
  * a fit grows past that (:605-611: it prints "out of Memory" and continues).  Here such a fit is FLAGGED
@@ -125,6 +131,13 @@ int pareben_cv_grid(const double *basis, int n, int p, const double *target,
                     double *fold_err, int32_t *status, int64_t *counters);
 
 /*
+ * The pairwise pass of GetLambdaMax (R/BuildGrid.R:21-30, the O(n p^2) double loop that dominates BuildGrid() with
+ * Epis = "yes"): *out = max over pairs i < j of  (x_i*x_j / |x_i*x_j|) . (Target - mean(Target)),  -inf when p < 2
+ * or every pair column is zero.  The caller combines it with the main-effect pass and the log(1.1) floor (:9-19).
+ */
+int pareben_lambda_max_pairs(const double *basis, int n, int p, const double *target, int device, double *out);
+
+/*
  * The same grid on n_gpu devices of one node from ONE host process (the caller is a single R session;
  * reference call site: the foreach over grid rows, R/CrossValidate.R:66-70, whose workers were separate R
  * processes): one host thread and context per device, BASIS / Target / fold ids replicated, the cells dealt
@@ -167,6 +180,17 @@ int pareben_fit_gaussian_epis(const double *basis, const double *target, double 
 int pareben_fit_binomial(const double *basis, const double *target, double lambda, double alpha,
                          double *logLikelihood, double *Beta, double *wald, double *intercept,
                          int n, int k, int verbose, int bMax, int device, int64_t *counters);
+
+/*
+ * Same for Epis = "yes" (EBEN_orig/R/EBelasticNet.Binomial.R:6-26, .C("ElasticNetBinaryNEfull"), i.e.
+ * EBEN_orig/src/ElasticNetBinaryNeFull.c:52): the k main effects plus the k(k-1)/2 pairwise columns.  Beta is
+ * bMax x 4 column-major with bMax = 2k as the R wrapper passes it, and -- unlike the tables above -- lists the
+ * USED bases in model order: (locus1, locus2, effect, posterior variance), zero rows after them
+ * (ElasticNetBinaryNeFull.c:154-211); a model may hold at most bMax bases.
+ */
+int pareben_fit_binomial_epis(const double *basis, const double *target, double lambda, double alpha,
+                              double *logLikelihood, double *Beta, double *wald, double *intercept,
+                              int n, int k, int verbose, int bMax, int device, int64_t *counters);
 
 #ifdef __cplusplus
 }

@@ -1,6 +1,19 @@
 /*
- * eben_bm.c -- oracle: binomial (logistic) main-effect EBEN fit ("Bm"), a CPU restatement of the
- * algorithm in EBEN_orig/src/ElasticNetBinaryNEmainEff.c.
+ * eben_bm.c -- oracle: binomial (logistic) EBEN fits, a CPU restatement of the algorithms in
+ * EBEN_orig/src/ElasticNetBinaryNEmainEff.c (main effects, "Bm") and
+ * EBEN_orig/src/ElasticNetBinaryNeFull.c (main effects + pairwise epistasis, "Bf").
+ *
+ * Bf is Bm's skeleton over K(K+1)/2 implicit columns (x_i, then x_i*x_j in the order (1,2),(1,3)..)
+ * with these differences, each cited where it is applied (`epis` switches them on):
+ *   block cut-off 0.99 instead of 0.90 (NeFull.c:254); phi = column / scale by division (:437-450, :755;
+ *   Bm multiplies by the reciprocal, NEmainEff.c:644-646, :1349-1350); pair columns are regenerated inside
+ *   every sweep with the reference's association ((x_i*phi)*w)*x_j (:925-931), (x_i*w)*x_j (:1471, :1583,
+ *   :1738), (x_i*x_j)*(w*phi) (:1356); Newton step: y clamped to [1e-5, 1-1e-5] before the residual, weights
+ *   < 1e-5 -> 1e-3 and > 1e5 -> 1e3 (:1042-1048), stop when ALL M gradient entries are small (:1085-1099);
+ *   delete downdates Sigma as S - (s_i/s_jj)*s_j (:1606); delete-priority only for more than 100 bases
+ *   (:1805-1809); the outer stopping sum runs over the M-1 precisions (:133-134); capacity bMax = 2K from
+ *   the R wrapper (EBelasticNet.Binomial.R:7-9), checked as N_used+1 > bMax (:549-553); output = the used
+ *   bases in model order, bMax x 4 (:154-211).
  *
  * TEST INFRASTRUCTURE ONLY (see eben_oracle.h).  Own data structures (state struct, 0-based
  * feature ids), the reference's arithmetic order (sequential sums, -ffp-contract=off) and its
@@ -20,7 +33,10 @@
 enum { ACT_NONE = -10, ACT_REEST = 0, ACT_ADD = 1, ACT_DEL = -1, ACT_TERM = 10 };
 
 typedef struct {
-    int N, K, cap;
+    int N, K, cap;             /* K = number of candidate columns: P, or P(P+1)/2 with epistasis */
+    int epis, P;               /* P = columns of X                                              */
+    int bmax;                  /* epistasis: the R wrapper's bMax = 2P                          */
+    int *fi, *fj;              /* epistasis: column f is x_fi (fj < 0) or x_fi * x_fj           */
     const double *X, *y;
     double lambda, alpha;
     double *scale;
@@ -56,6 +72,14 @@ static double data_error(double *y, const double *pm, const double *t, int n)
     return e;
 }
 
+/* candidate column f at sample h (used only where the reference forms the product this way) */
+static double col_at(const bm *s, int f, int h)
+{
+    const int N = s->N;
+    if (!s->epis || s->fj[f] < 0) return s->X[(size_t)(s->epis ? s->fi[f] : f) * N + h];
+    return s->X[(size_t)s->fi[f] * N + h] * s->X[(size_t)s->fj[f] * N + h];
+}
+
 static void phi_mu(const bm *s, const double *mu, int M, double *out)
 {
     const int N = s->N;
@@ -83,12 +107,16 @@ static void bm_postmode(bm *s)
     for (int it = 0; it < 25; it++) {
         elog[it] = total;
         double g0 = 0, h0 = 0;
+        if (s->epis) for (int j = 0; j < N; j++) {         /* NeFull.c:1042-1043 */
+            if (y[j] < 1e-5) y[j] = 1e-5;
+            if (y[j] > (1 - 1e-5)) y[j] = 1 - 1e-5;
+        }
         for (int j = 0; j < N; j++) { e[j] = s->y[j] + -1.0 * y[j]; }
         for (int j = 0; j < N; j++) g0 = g0 + 1.0 * e[j];
         for (int j = 0; j < N; j++) {
             double b = y[j] * (1 - y[j]);
-            if (b < 1e-10) b = 1e-5;
-            if (b > 1e10) b = 1e5;
+            if (s->epis) { if (b < 1e-5) b = 1e-3; if (b > 1e5) b = 1e3; }      /* NeFull.c:1047-1048 */
+            else { if (b < 1e-10) b = 1e-5; if (b > 1e10) b = 1e5; }            /* NEmainEff.c:1878-1883 */
             s->w[j] = b;
         }
         for (int j = 0; j < N; j++) h0 = h0 + 1.0 * s->w[j];
@@ -111,8 +139,8 @@ static void bm_postmode(bm *s)
         memcpy(s->Sig, s->H, sizeof(double) * (size_t)M * M);
         if (chol_inverse_upper(s->Sig, M)) s->c.status |= 2;
         int cnt = 0;
-        for (int j = 1; j < M; j++) if (fabs(g[j]) < 1e-6) cnt++;
-        if (cnt == M - 1) break;
+        for (int j = s->epis ? 0 : 1; j < M; j++) if (fabs(g[j]) < 1e-6) cnt++;   /* NeFull.c:1085-1099 counts the intercept too */
+        if (cnt == (s->epis ? M : M - 1)) break;
         for (int k = 0; k < M; k++) {
             double a = 0;
             for (int L = 0; L < M; L++) a = a + g[L] * s->Sig[(size_t)L * M + k];
@@ -147,17 +175,33 @@ static void bm_fullstat(bm *s)
     sigmoid_vec(y, pm, N);
     for (int i = 0; i < N; i++) e[i] = s->y[i] + -1.0 * y[i];
     for (int i = 0; i < K; i++) {
-        const double *x = s->X + (size_t)i * N;
-        for (int p = 0; p < M; p++) {
-            const double *ph = s->Phi + (size_t)p * N;
-            double a = 0;
-            for (int j = 0; j < N; j++) a = a + x[j] * ph[j] * s->w[j];
-            bp[p] = a / s->scale[i];
+        const int ci = s->epis ? s->fi[i] : i, cj = s->epis ? s->fj[i] : -1;
+        const double *x = s->X + (size_t)ci * N;
+        double bb = 0, ze = 0;
+        if (cj < 0) {
+            for (int p = 0; p < M; p++) {
+                const double *ph = s->Phi + (size_t)p * N;
+                double a = 0;
+                for (int j = 0; j < N; j++) a = a + x[j] * ph[j] * s->w[j];
+                bp[p] = a / s->scale[i];
+            }
+            bb = dot_seq(N, s->w, s->x2 + (size_t)ci * N);
+            ze = dot_seq(N, x, e);
+        } else {                                        /* pair column, NeFull.c:921-957 */
+            const double *xl = s->X + (size_t)cj * N;
+            for (int p = 0; p < M; p++) {
+                const double *ph = s->Phi + (size_t)p * N;
+                double a = 0;
+                for (int j = 0; j < N; j++) a = a + x[j] * ph[j] * s->w[j] * xl[j];
+                bp[p] = a / s->scale[i];
+            }
+            for (int p = 0; p < N; p++) {
+                bb = bb + s->w[p] * s->x2[(size_t)ci * N + p] * s->x2[(size_t)cj * N + p];
+                ze = ze + x[p] * e[p] * xl[p];
+            }
         }
         for (int p = 0; p < M; p++) tmp[p] = dot_seq(M, s->Sig + (size_t)p * M, bp);
         double quad = dot_seq(M, tmp, bp);
-        double bb = dot_seq(N, s->w, s->x2 + (size_t)i * N);
-        double ze = dot_seq(N, x, e);
         s->Sin[i] = bb / (s->scale[i] * s->scale[i]) - quad;
         s->Qin[i] = ze / s->scale[i];
         s->Sout[i] = s->Sin[i];
@@ -181,7 +225,7 @@ static int bm_delta_ml(bm *s, int *any_del, double *best)
     int prio_add = 0, prio_del = 0;
     *any_del = 0;
     if (NU < 10) { prio_add = 1; prio_del = 0; }
-    if (NU > 100 || NU >= N) { prio_add = 0; prio_del = 1; }
+    if (NU > 100 || (!s->epis && NU >= N)) { prio_add = 0; prio_del = 1; }   /* NeFull.c:1805-1809 has no N clause */
     for (int i = 0; i < K; i++) s->act[i] = ACT_NONE;
     double dmax = 0; int imax = 0;
     for (int i = 0; i < NU; i++) {
@@ -245,11 +289,14 @@ static int bm_delta_ml(bm *s, int *any_del, double *best)
 static void weighted_row(const bm *s, int i, int M, double *out)
 {
     const int N = s->N;
-    const double *x = s->X + (size_t)i * N;
+    const int ci = s->epis ? s->fi[i] : i, cj = s->epis ? s->fj[i] : -1;
+    const double *x = s->X + (size_t)ci * N;
+    const double *xl = cj >= 0 ? s->X + (size_t)cj * N : NULL;
     for (int j = 0; j < M; j++) {
         const double *ph = s->Phi + (size_t)j * N;
         double a = 0;
-        for (int h = 0; h < N; h++) a = a + (x[h] * s->w[h]) * ph[h];
+        if (!xl) for (int h = 0; h < N; h++) a = a + (x[h] * s->w[h]) * ph[h];
+        else     for (int h = 0; h < N; h++) a = a + (x[h] * s->w[h] * xl[h]) * ph[h];   /* NeFull.c:1471, :1583, :1738 */
         out[j] = a / s->scale[i];
     }
 }
@@ -264,9 +311,11 @@ static void bm_add(bm *s, int nu, double newA, const double *phi)
     double *SN = (double *)calloc((size_t)M1 * M1, sizeof(double));
     for (int j = 0; j < N; j++) bphi[j] = s->w[j] * phi[j];
     for (int i = 0; i < K; i++) {
-        const double *x = s->X + (size_t)i * N;
+        const int ci = s->epis ? s->fi[i] : i, cj = s->epis ? s->fj[i] : -1;
+        const double *x = s->X + (size_t)ci * N;
         double a = 0;
-        for (int h = 0; h < N; h++) a = a + x[h] * bphi[h];
+        if (cj < 0) for (int h = 0; h < N; h++) a = a + x[h] * bphi[h];
+        else { const double *xl = s->X + (size_t)cj * N; for (int h = 0; h < N; h++) a = a + x[h] * xl[h] * bphi[h]; }   /* NeFull.c:1356 */
         bb[i] = a / s->scale[i];
     }
     for (int i = 0; i < M; i++) tmp[i] = dot_seq(N, s->Phi + (size_t)i * N, bphi);
@@ -316,7 +365,8 @@ static void bm_delete(bm *s, int jj, int nu)
     }
     for (int i = 0; i < M; i++)
         for (int j = 0; j < M; j++)
-            T[(size_t)j * M + i] = Sg[(size_t)j * M + i] - Sg[(size_t)j1 * M + i] * Sg[(size_t)j1 * M + j] / sjj;
+            T[(size_t)j * M + i] = s->epis ? Sg[(size_t)j * M + i] - Sg[(size_t)j1 * M + i] / sjj * Sg[(size_t)j1 * M + j]      /* NeFull.c:1606 */
+                                           : Sg[(size_t)j * M + i] - Sg[(size_t)j1 * M + i] * Sg[(size_t)j1 * M + j] / sjj;     /* NEmainEff.c:1069 */
     for (int i = 0; i < last; i++)
         for (int j = 0; j < last; j++) SN[(size_t)j * last + i] = T[(size_t)j * M + i];
     if (j1 != last) {
@@ -372,7 +422,8 @@ static void bm_initialise(bm *s, int first)
         s->used[0] = 0;
         for (int i = 0; i < N; i++) s->Phi[i] = 1;
         double r = 1 / s->scale[0];
-        for (int i = 0; i < N; i++) s->Phi[N + i] = s->X[i] * r;
+        if (s->epis) for (int i = 0; i < N; i++) s->Phi[N + i] = s->X[i] / s->scale[0];     /* NeFull.c:755 */
+        else         for (int i = 0; i < N; i++) s->Phi[N + i] = s->X[i] * r;               /* NEmainEff.c:1349-1350 */
         double sa = 0, sb = 0, sc = 0, sd = 0;
         for (int i = 0; i < N; i++) {
             double tp = -1 + 2 * s->y[i];
@@ -427,7 +478,7 @@ static int bm_inner(bm *s, int iter, double *loglik)
             ini_removed = 1; sel = ACT_DEL;
         } else {
             worthwhile = 1;
-            double cutoff = best * (s->act[nu] == ACT_ADD ? 0.90 : 1.0);
+            double cutoff = best * (s->act[nu] == ACT_ADD ? (s->epis ? 0.99 : 0.90) : 1.0);      /* NeFull.c:254 | NEmainEff.c:422 */
             if (cutoff < 0.001) cutoff = 0.001;
             n_todo = 0;
             for (int i = 0; i < K; i++) if (s->dml[i] >= cutoff) s->todo[n_todo++] = i;
@@ -446,13 +497,16 @@ static int bm_inner(bm *s, int iter, double *loglik)
                     if (!found) { s->c.status |= 4; if (jj < 0 || jj >= s->n_used) { free(phi); free(pm); return 1; } }
                 }
                 double r = 1.0 / s->scale[nu];
-                for (int h = 0; h < N; h++) phi[h] = s->X[(size_t)nu * N + h] * r;
+                if (s->epis) for (int h = 0; h < N; h++) phi[h] = col_at(s, nu, h) / s->scale[nu];   /* NeFull.c:437-450 */
+                else         for (int h = 0; h < N; h++) phi[h] = s->X[(size_t)nu * N + h] * r;
                 if (sel == ACT_REEST && fabs(log(newA) - log(s->A[jj])) <= 1e-3 && any_del == 0) sel = ACT_TERM;
                 if (sel == ACT_REEST) {
                     s->c.n_reest++; s->c.sum_m_action += M_OF(s);
                     bm_reestimate(s, jj, newA);
                 } else if (sel == ACT_ADD) {
                     if (s->n_used + 2 > s->cap) { s->c.status |= 1; free(phi); free(pm); return 1; }
+                    /* NeFull.c:549-553 (the reference tests this from the second outer iteration on and overruns its arrays in the first) */
+                    if (s->epis && s->n_used + 1 > s->bmax) { s->c.status |= 1; free(phi); free(pm); return 1; }
                     s->c.n_add++; s->c.sum_m_action += M_OF(s);
                     bm_add(s, nu, newA, phi);
                 } else if (sel == ACT_DEL) {
@@ -480,24 +534,11 @@ static int bm_inner(bm *s, int iter, double *loglik)
     return 0;
 }
 
-int eben_bm_fit(const double *X, const double *y, int N, int K, double lambda, double alpha,
-                double *loglik, double *Beta, double *wald, double *intercept, eben_counters *cnt)
+static void bm_alloc(bm *s, int cap)
 {
-    bm S; memset(&S, 0, sizeof(S));
-    bm *s = &S;
-    s->N = N; s->K = K; s->X = X; s->y = y; s->lambda = lambda; s->alpha = alpha;
-    const int cap = K + 2;                          /* R passes bMax = K (EBelasticNet.Binomial.R:28,45) */
+    const int N = s->N, K = s->K;
     s->cap = cap;
-    s->scale = (double *)calloc(K, sizeof(double));
-    s->x2 = (double *)calloc((size_t)N * K, sizeof(double));
-    for (int i = 0; i < K; i++) {
-        Beta[i] = i + 1; Beta[K + i] = i + 1; Beta[2 * (size_t)K + i] = 0; Beta[3 * (size_t)K + i] = 0;
-        double q = dot_seq(N, X + (size_t)i * N, X + (size_t)i * N);
-        if (q == 0) q = 1;
-        s->scale[i] = sqrt(q);
-        for (int j = 0; j < N; j++) s->x2[(size_t)i * N + j] = X[(size_t)i * N + j] * X[(size_t)i * N + j];
-    }
-    s->used = (int *)calloc(cap, sizeof(int)); s->unused = (int *)calloc(K + 1, sizeof(int));
+    s->used = (int *)calloc(cap, sizeof(int)); s->unused = (int *)calloc((size_t)K + 1, sizeof(int));
     s->A = (double *)calloc(cap + 1, sizeof(double)); s->mu = (double *)calloc(cap + 1, sizeof(double));
     s->Sig = (double *)calloc((size_t)(cap + 1) * (cap + 1), sizeof(double));
     s->H = (double *)calloc((size_t)(cap + 1) * (cap + 1), sizeof(double));
@@ -508,19 +549,53 @@ int eben_bm_fit(const double *X, const double *y, int N, int K, double lambda, d
     s->dml = (double *)calloc(K, sizeof(double)); s->aroot = (double *)calloc(K, sizeof(double));
     s->act = (int *)calloc(K, sizeof(int)); s->todo = (int *)calloc(K, sizeof(int));
     s->n_used = 1;
-    double vk = 1e-30, vk0, err = 1000, ll = 0;
+}
+
+static void bm_free(bm *s)
+{
+    free(s->scale); free(s->x2); free(s->used); free(s->unused); free(s->A); free(s->mu); free(s->Sig); free(s->H);
+    free(s->Phi); free(s->w); free(s->Sin); free(s->Qin); free(s->Sout); free(s->Qout); free(s->dml); free(s->aroot);
+    free(s->act); free(s->todo); free(s->fi); free(s->fj);
+}
+
+/* outer loop: NEmainEff.c:329-344 / NeFull.c:121-137 */
+static int bm_outer(bm *s, double *ll)
+{
+    double vk = 1e-30, vk0, err = 1000;
     int iter = 0, rc = 0;
-    while (iter < 100 && err > 1e-8) {                             /* :329-344 */
+    while (iter < 100 && err > 1e-8) {
         iter++;
         vk0 = vk;
-        rc = bm_inner(s, iter, &ll);
+        rc = bm_inner(s, iter, ll);
         if (rc) break;
         const int M = M_OF(s);
         vk = 0;
-        for (int i = 0; i < M; i++) vk += fabs(s->A[i]);          /* dasum over M = N_used+1 (Q12) */
+        if (s->epis) for (int i = 0; i < M - 1; i++) vk = vk + s->A[i];   /* NeFull.c:133-134: the M-1 precisions */
+        else         for (int i = 0; i < M; i++) vk += fabs(s->A[i]);     /* dasum over M = N_used+1 (Q12) */
         err = fabs(vk - vk0) / M;
     }
     s->c.n_outer = iter;
+    return rc;
+}
+
+int eben_bm_fit(const double *X, const double *y, int N, int K, double lambda, double alpha,
+                double *loglik, double *Beta, double *wald, double *intercept, eben_counters *cnt)
+{
+    bm S; memset(&S, 0, sizeof(S));
+    bm *s = &S;
+    s->N = N; s->K = K; s->P = K; s->X = X; s->y = y; s->lambda = lambda; s->alpha = alpha;
+    s->scale = (double *)calloc(K, sizeof(double));
+    s->x2 = (double *)calloc((size_t)N * K, sizeof(double));
+    for (int i = 0; i < K; i++) {
+        Beta[i] = i + 1; Beta[K + i] = i + 1; Beta[2 * (size_t)K + i] = 0; Beta[3 * (size_t)K + i] = 0;
+        double q = dot_seq(N, X + (size_t)i * N, X + (size_t)i * N);
+        if (q == 0) q = 1;
+        s->scale[i] = sqrt(q);
+        for (int j = 0; j < N; j++) s->x2[(size_t)i * N + j] = X[(size_t)i * N + j] * X[(size_t)i * N + j];
+    }
+    bm_alloc(s, K + 2);                             /* R passes bMax = K (EBelasticNet.Binomial.R:28,45) */
+    double ll = 0;
+    int rc = bm_outer(s, &ll);
     {
         const int M = M_OF(s);
         double *tw = (double *)calloc(M, sizeof(double));
@@ -538,8 +613,71 @@ int eben_bm_fit(const double *X, const double *y, int N, int K, double lambda, d
     *loglik = ll;
     s->c.m_final = s->n_used;
     if (cnt) *cnt = s->c;
-    free(s->scale); free(s->x2); free(s->used); free(s->unused); free(s->A); free(s->mu); free(s->Sig); free(s->H);
-    free(s->Phi); free(s->w); free(s->Sin); free(s->Qin); free(s->Sout); free(s->Qout); free(s->dml); free(s->aroot);
-    free(s->act); free(s->todo);
+    bm_free(s);
+    return rc;
+}
+
+/* Binomial, main effects + pairwise epistasis: EBEN_orig/src/ElasticNetBinaryNeFull.c:52-232.
+ * Beta is bMax x 4 column-major and lists the USED bases in model order (locus1, locus2, effect, variance),
+ * zero rows after them (:66, :154-211); the R wrapper passes bMax = 2K (EBelasticNet.Binomial.R:7-9, :25). */
+int eben_bf_fit(const double *X, const double *y, int N, int K, double lambda, double alpha,
+                double *loglik, double *Beta, int bMax, double *wald, double *intercept, eben_counters *cnt)
+{
+    bm S; memset(&S, 0, sizeof(S));
+    bm *s = &S;
+    const long MF = (long)K * (K + 1) / 2;
+    s->N = N; s->K = (int)MF; s->P = K; s->epis = 1; s->bmax = bMax;
+    s->X = X; s->y = y; s->lambda = lambda; s->alpha = alpha;
+    s->scale = (double *)calloc(MF, sizeof(double));
+    s->x2 = (double *)calloc((size_t)N * K, sizeof(double));     /* basisCache: squares of the K main columns only (:291-296) */
+    s->fi = (int *)calloc(MF, sizeof(int)); s->fj = (int *)calloc(MF, sizeof(int));
+    for (int i = 0; i < 4 * bMax; i++) Beta[i] = 0;               /* as allocated by R; the reference clears column 3 (:66) */
+    for (int i = 0; i < K; i++) {                                 /* :79-88 */
+        double q = 0;
+        for (int l = 0; l < N; l++) { q = q + X[(size_t)i * N + l] * X[(size_t)i * N + l]; s->x2[(size_t)i * N + l] = X[(size_t)i * N + l] * X[(size_t)i * N + l]; }
+        if (q == 0) q = 1;
+        s->scale[i] = sqrt(q);
+        s->fi[i] = i; s->fj[i] = -1;
+    }
+    long kk = K;
+    for (int i = 0; i < K - 1; i++)                               /* :90-105 */
+        for (int j = i + 1; j < K; j++) {
+            double q = 0;
+            const double *xi = X + (size_t)i * N, *xj = X + (size_t)j * N;
+            for (int l = 0; l < N; l++) q = q + xi[l] * xi[l] * xj[l] * xj[l];
+            if (q == 0) q = 1;
+            s->scale[kk] = sqrt(q);
+            s->fi[kk] = i; s->fj[kk] = j;
+            kk++;
+        }
+    bm_alloc(s, bMax + 2);
+    double ll = 0;
+    int rc = bm_outer(s, &ll);
+    {
+        const int M = M_OF(s);
+        double *tw = (double *)calloc(M, sizeof(double));
+        *wald = 0;
+        for (int i = 0; i < M; i++) {                             /* :146-153 */
+            tw[i] = 0;
+            for (int j = 0; j < M; j++) tw[i] = tw[i] + s->mu[j] * s->H[(size_t)i * M + j];
+            *wald = *wald + tw[i] * s->mu[i];
+        }
+        free(tw);
+        int meff = M - 1;
+        if (M > bMax) meff = bMax;                                /* :163-167 */
+        for (int i = 0; i < meff; i++) {
+            const int f = s->used[i];
+            Beta[i] = s->fi[f] + 1;                               /* the reference decodes (locus1, locus2) from the column id, :172-199 */
+            Beta[bMax + i] = (s->fj[f] < 0 ? s->fi[f] : s->fj[f]) + 1;
+            Beta[2 * (size_t)bMax + i] = s->mu[i + 1] / s->scale[f];
+            Beta[3 * (size_t)bMax + i] = s->Sig[(size_t)(i + 1) * M + i + 1] / (s->scale[f] * s->scale[f]);
+        }
+        intercept[0] = s->mu[0];
+        intercept[1] = s->Sig[0];
+    }
+    *loglik = ll;
+    s->c.m_final = s->n_used;
+    if (cnt) *cnt = s->c;
+    bm_free(s);
     return rc;
 }

@@ -97,8 +97,10 @@ int eben_cv_grid(const double *basis, int n, int p, const double *y, const int32
             }
         }
     }
-    const long n_eff = epis ? (long)p * (p + 1) / 2 : p;
-    const int bcols = epis ? 5 : 4;
+    /* rows of the fit's Beta table: K (main effects), K(K+1)/2 (gaussian + epistasis: every implicit column), or the R
+     * wrapper's bMax = 2K used-bases list of the binomial + epistasis fit (EBelasticNet.Binomial.R:7-9) */
+    const long n_eff = (epis && prior == 1) ? 2L * p : (epis ? (long)p * (p + 1) / 2 : p);
+    const int bcols = (epis && prior == 0) ? 5 : 4;
     int rc_all = 0;
     eben_counters total; memset(&total, 0, sizeof(total));
 #ifdef _OPENMP
@@ -113,7 +115,8 @@ int eben_cv_grid(const double *basis, int n, int p, const double *y, const int32
         int rc;
         if (prior == 0 && !epis) rc = eben_gm_fit(Xtr[f], ytr[f], ntr[f], p, lambda[c], alpha[c], Beta, &wald, icpt, &resid, &k);
         else if (prior == 0)     rc = eben_gf_fit(Xtr[f], ytr[f], ntr[f], p, lambda[c], alpha[c], Beta, &wald, icpt, &resid, &k);
-        else                     rc = eben_bm_fit(Xtr[f], ytr[f], ntr[f], p, lambda[c], alpha[c], &ll, Beta, &wald, icpt, &k);
+        else if (!epis)          rc = eben_bm_fit(Xtr[f], ytr[f], ntr[f], p, lambda[c], alpha[c], &ll, Beta, &wald, icpt, &k);
+        else                     rc = eben_bf_fit(Xtr[f], ytr[f], ntr[f], p, lambda[c], alpha[c], &ll, Beta, (int)n_eff, &wald, icpt, &k);
         double err;
         if (prior == 0) err = fold_sse(Xte[f], yte[f], nte[f], p, Beta, n_eff, epis, icpt[0]);
         else            err = fold_loglik(Xte[f], yte[f], nte[f], p, Beta, n_eff, icpt[0]);

@@ -53,6 +53,12 @@ int eben_bm_fit(const double *X, const double *y, int N, int K, double lambda, d
                 double *loglik, double *Beta, double *wald, double *intercept,
                 eben_counters *cnt);
 
+/* Binomial, main + pairwise epistasis.  Follows EBEN_orig/src/ElasticNetBinaryNeFull.c:52-232.
+ * Beta is bMax x 4 column-major: the used bases in model order (locus1, locus2, beta, var); R passes bMax = 2K. */
+int eben_bf_fit(const double *X, const double *y, int N, int K, double lambda, double alpha,
+                double *loglik, double *Beta, int bMax, double *wald, double *intercept,
+                eben_counters *cnt);
+
 /* Whole CV grid: for each cell c and fold f (1..n_folds) fit on rows fold_id != f and score the
  * rows fold_id == f exactly as R/TestModel.R:6-39 + R/GetModelError.R:6-59 do.
  * prior: 0 gaussian (fold SSE), 1 binomial (mean log-lik).  epis: 0/1.

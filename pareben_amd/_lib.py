@@ -41,9 +41,11 @@ def load():
     L.pareben_ctx_gram.argtypes = [C.c_void_p, C.c_int, dp]
     L.pareben_cv_grid.argtypes = [dp, C.c_int, C.c_int, dp, ip, C.c_int, dp, dp, C.c_int, C.c_int, C.c_int, C.c_int, dp, ip, lp]
     L.pareben_cv_grid_multi.argtypes = L.pareben_cv_grid.argtypes
+    L.pareben_lambda_max_pairs.argtypes = [dp, C.c_int, C.c_int, dp, C.c_int, dp]
     L.pareben_fit_gaussian.argtypes = [dp, dp, C.c_double, C.c_double, dp, dp, dp, C.c_int, C.c_int, C.c_int, dp, C.c_int, lp]
     L.pareben_fit_gaussian_epis.argtypes = L.pareben_fit_gaussian.argtypes
     L.pareben_fit_binomial.argtypes = [dp, dp, C.c_double, C.c_double, dp, dp, dp, dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, lp]
+    L.pareben_fit_binomial_epis.argtypes = L.pareben_fit_binomial.argtypes
     _lib = L
     return L
 
@@ -75,6 +77,8 @@ class Context:
         fid = np.ascontiguousarray(fold_id, dtype=np.int32).reshape(-1)
         if X.ndim != 2 or y.shape[0] != X.shape[0] or fid.shape[0] != X.shape[0]:
             raise ValueError("BASIS must be n x p and Target / fold_id must have n entries")
+        if prior not in ("gaussian", "binomial"):
+            raise ValueError('prior must be "gaussian" or "binomial"')
         self.n, self.p = X.shape
         self.n_folds = int(n_folds)
         self.epis = bool(epis)
@@ -131,6 +135,15 @@ class Context:
             pass
 
 
+def lambda_max_pairs(BASIS, Target, device=0):
+    """pareben_lambda_max_pairs: the pairwise pass of GetLambdaMax (R/BuildGrid.R:21-30) on the GPU -> float (-inf if no pair counts)."""
+    X = np.asfortranarray(BASIS, dtype=np.float64)
+    y = np.ascontiguousarray(Target, dtype=np.float64).reshape(-1)
+    out = C.c_double(0)
+    _chk(load().pareben_lambda_max_pairs(_dp(X), X.shape[0], X.shape[1], _dp(y), int(device), C.byref(out)), "pareben_lambda_max_pairs")
+    return out.value
+
+
 def cv_grid_multi(BASIS, Target, fold_id, n_folds, alpha, lam, prior="gaussian", epis=False, n_gpu=0, want_counters=True):
     """pareben_cv_grid_multi: the grid on n_gpu devices from this one process (one host thread + context per device,
     one RCCL all-gather of the per-cell results); n_gpu <= 0 = every visible device.
@@ -170,18 +183,20 @@ def fit_gaussian(BASIS, Target, lam, alpha, device=0, epis=False):
                 counters=dict(zip(COUNTER_NAMES, (int(v) for v in cnt))))
 
 
-def fit_binomial(BASIS, Target, lam, alpha, device=0):
-    """Mirror of the reference's .C("ElasticNetBinaryNEmainEff") tuple (EBEN_orig/R/EBelasticNet.Binomial.R:32-46)
-    -> dict(Beta K x 4, logLikelihood, wald, intercept[2] = (mu0, Sigma00), counters)."""
+def fit_binomial(BASIS, Target, lam, alpha, device=0, epis=False):
+    """Mirror of the reference's .C("ElasticNetBinaryNEmainEff") / .C("ElasticNetBinaryNEfull") tuples
+    (EBEN_orig/R/EBelasticNet.Binomial.R:6-46) -> dict(Beta, logLikelihood, wald, intercept[2] = (mu0, Sigma00), counters).
+    Beta: K x 4 indexed by column (main effects), or 2K x 4 listing the used bases in model order (Epis = "yes")."""
     L = load()
     X = np.asfortranarray(BASIS, dtype=np.float64)
     y = np.ascontiguousarray(Target, dtype=np.float64).reshape(-1)
     n, k = X.shape
-    Beta = np.zeros((k, 4), order="F")
+    Beta = np.zeros((2 * k if epis else k, 4), order="F")
     ll, wald = C.c_double(0), C.c_double(0)
     icpt = np.zeros(2)
     cnt = np.zeros(NCOUNTERS, dtype=np.int64)
-    _chk(L.pareben_fit_binomial(_dp(X), _dp(y), float(lam), float(alpha), C.byref(ll), _dp(Beta), C.byref(wald), _dp(icpt),
-                                n, k, 0, k, int(device), _lp(cnt)), "pareben_fit_binomial")
+    fn, name = (L.pareben_fit_binomial_epis, "pareben_fit_binomial_epis") if epis else (L.pareben_fit_binomial, "pareben_fit_binomial")
+    _chk(fn(_dp(X), _dp(y), float(lam), float(alpha), C.byref(ll), _dp(Beta), C.byref(wald), _dp(icpt),
+            n, k, 0, 2 * k if epis else k, int(device), _lp(cnt)), name)
     return dict(Beta=Beta, logLikelihood=ll.value, wald=wald.value, intercept=icpt,
                 counters=dict(zip(COUNTER_NAMES, (int(v) for v in cnt))))

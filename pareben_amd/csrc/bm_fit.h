@@ -1,4 +1,16 @@
-// bm_fit.h -- one binomial (logistic) main-effect EBEN fit executed by ONE workgroup.
+// bm_fit.h -- one binomial (logistic) EBEN fit executed by ONE workgroup: main effects
+// (ElasticNetBinaryNEmainEff.c, "Bm") or main effects + pairwise epistasis (ElasticNetBinaryNeFull.c, "Bf").
+//
+// Bf runs the same code on the expanded design (expand_kernel: the K main columns followed by the pair
+// columns x_i*x_j in the reference's order) with the rule set in which NeFull.c differs from NEmainEff.c,
+// each cited where `S.v.epis` / `W.phi_div` switches it: block cut-off 0.99 (:254), phi = column / scale by
+// division (:437-450, :755), Newton step with y clamped to [1e-5, 1-1e-5] and weights < 1e-5 -> 1e-3,
+// > 1e5 -> 1e3 (:1042-1048) that stops when ALL M gradient entries are small (:1085-1099), Sigma downdate of a
+// delete associated as S - (s_i/s_jj) s_j (:1606), delete-priority only above 100 bases (:1805-1809), outer
+// stopping sum over the M-1 precisions (:133-134), capacity bMax = 2K bases from the R wrapper
+// (EBelasticNet.Binomial.R:7-9; NeFull.c:549-553).  The reference regenerates a pair column inside every
+// sweep and associates its products as ((x_i*phi)*w)*x_j etc.; on the materialised column the same products
+// round differently in the last bit for non-integer designs (exactly equal for genotype codes -1/0/1).
 //
 // What it computes is what EBEN_orig/src/ElasticNetBinaryNEmainEff.c computes for one
 // (training fold, alpha, lambda): the outer loop (:329-344) around the inner
@@ -32,10 +44,18 @@ struct BmWork {
     double *w, *pm, *yv, *e, *bphi;                        // Nmax each
     double *BP;                                            // K x ld (row i = feature i)
     int cap, ld;                                           // cap = max model size M, ld = cap
+    int phi_div;                                           // Bf: model column = x / |x| (division); Bm: x * (1/|x|)
+    int bmax;                                              // Bf: most bases a model may hold (the R wrapper's bMax = 2K); Bm: unused (cap decides)
 };
 
+// design column u, normalised, at sample h: NEmainEff.c:644-646 multiplies by the reciprocal norm, NeFull.c:437-450 divides
+DEV double bm_col(const FoldDev &F, const BmWork &W, int N, int u, int h)
+{
+    const double x = F.X[(size_t)u * N + h];
+    return W.phi_div ? x / F.scale[u] : x * F.rscale[u];
+}
 // model column p at sample h
-#define BM_PHI(p, h) ((p) == 0 ? 1.0 : F.X[(size_t)W.used[(p) - 1] * N + (h)] * F.rscale[W.used[(p) - 1]])
+#define BM_PHI(p, h) ((p) == 0 ? 1.0 : bm_col(F, W, N, W.used[(p) - 1], (h)))
 
 // a GmWork view so the Gaussian kernel's SPD inverse can be reused on (Sig, ld)
 DEV GmWork bm_as_gm(const BmWork &W)
@@ -141,9 +161,7 @@ DEVNI void bm_weighted_rows(const Blk &B, const FoldDev &F, const BmWork &W, int
                 if (p == 0) { for (int h = B.lane; h < N; h += 64) a += x[h] * W.w[h]; }
                 else {
                     const int u = W.used[p - 1];
-                    const double *xu = F.X + (size_t)u * N;
-                    const double r = F.rscale[u];
-                    for (int h = B.lane; h < N; h += 64) a += (x[h] * W.w[h]) * (xu[h] * r);
+                    for (int h = B.lane; h < N; h += 64) a += (x[h] * W.w[h]) * bm_col(F, W, N, u, h);
                 }
                 a = wave_sum(a);
                 if (B.lane == 0) W.BP[(size_t)i * ld + p] = a / F.scale[i];
@@ -168,12 +186,16 @@ DEVNI int bm_postmode(const Blk &B, const FoldDev &F, const BmWork &W, GmScalars
         const double elog = total;
         double gp = 0, hp = 0;
         PAR(h, N) {
-            const double y = W.yv[h];
+            double y = W.yv[h];
+            if (S.v.epis) {                                    // NeFull.c:1042-1043
+                if (y < 1e-5) y = 1e-5;
+                if (y > (1 - 1e-5)) y = 1 - 1e-5;
+            }
             const double e = F.y[h] - y;
             W.e[h] = e;
             double b = y * (1 - y);
-            if (b < 1e-10) b = 1e-5;
-            if (b > 1e10) b = 1e5;
+            if (S.v.epis) { if (b < 1e-5) b = 1e-3; if (b > 1e5) b = 1e3; }       // NeFull.c:1047-1048
+            else { if (b < 1e-10) b = 1e-5; if (b > 1e10) b = 1e5; }             // NEmainEff.c:1878-1883
             W.w[h] = b;
             gp += e; hp += b;
         }
@@ -209,10 +231,8 @@ DEVNI int bm_postmode(const Blk &B, const FoldDev &F, const BmWork &W, GmScalars
                 const int k = q - j * (j + 1) / 2 + 1;
                 j += 1;                                        // 1 <= k <= j <= M-1
                 const int uj = W.used[j - 1], uk = W.used[k - 1];
-                const double *xj = F.X + (size_t)uj * N, *xk = F.X + (size_t)uk * N;
-                const double rj = F.rscale[uj], rk = F.rscale[uk];
                 double a = 0;
-                for (int h = B.lane; h < N; h += 64) a += (xj[h] * rj) * W.w[h] * (xk[h] * rk);
+                for (int h = B.lane; h < N; h += 64) a += bm_col(F, W, N, uj, h) * W.w[h] * bm_col(F, W, N, uk, h);
                 a = wave_sum(a);
                 if (B.lane == 0) {
                     if (j == k) a += W.A[k - 1];
@@ -232,9 +252,9 @@ DEVNI int bm_postmode(const Blk &B, const FoldDev &F, const BmWork &W, GmScalars
         }
         blk_sync(B);
         int cp = 0;
-        PAR(j, M) if (j >= 1 && fabs(W.g[j]) < 1e-6) cp++;
+        PAR(j, M) if ((j >= 1 || S.v.epis) && fabs(W.g[j]) < 1e-6) cp++;   // NeFull.c:1085-1099 counts the intercept's entry too
         const int cnt = blk_isum(B, cp);
-        if (cnt == M - 1) break;
+        if (cnt == (S.v.epis ? M : M - 1)) break;
         PAR(k, M) {
             double a = 0;
             for (int L = 0; L < M; L++) a += W.g[L] * W.Sig[(size_t)L * ld + k];
@@ -327,12 +347,12 @@ DEVNI int bm_fullstat(const Blk &B, const FoldDev &F, const BmWork &W, int K, Gm
 
 // dML / action choice, :2063-2238 (Q15: only delete-priority can fire)
 DEVNI int bm_delta_ml(const Blk &B, const BmWork &W, int K, int N, int NU, double lambda, double alpha,
-                      int *any_del_out, double *best)
+                      int epis, int *any_del_out, double *best)
 {
     const double l1 = lambda * alpha, l2 = lambda * (1 - alpha);
     int prio_add = 0, prio_del = 0;
     if (NU < 10) { prio_add = 1; prio_del = 0; }
-    if (NU > 100 || NU >= N) { prio_add = 0; prio_del = 1; }
+    if (NU > 100 || (!epis && NU >= N)) { prio_add = 0; prio_del = 1; }   // NeFull.c:1805-1809 has no N clause
     int my_del = 0;
     PAR(i, K) {
         const int l = W.upos[i];
@@ -411,8 +431,7 @@ DEVNI int bm_collect(const Blk &B, const BmWork &W, int K, double cutoff)
 DEVNI void bm_add(const Blk &B, const FoldDev &F, const BmWork &W, int K, GmScalars &S, int nu, double newA)
 {
     const int N = F.N, M = S.M, ld = W.ld, NU = M - 1;
-    const double rn = F.rscale[nu];
-    PAR(h, N) W.bphi[h] = W.w[h] * (F.X[(size_t)nu * N + h] * rn);
+    PAR(h, N) W.bphi[h] = W.w[h] * bm_col(F, W, N, nu, h);
     blk_sync(B);
     // bb[i] = x_i' (w .* phi) / |x_i| ; tmp[p] = Phi_p' (w .* phi)
 #ifdef PAREBEN_HOST_EMUL
@@ -498,7 +517,8 @@ DEVNI void bm_delete(const Blk &B, const FoldDev &F, const BmWork &W, int K, GmS
     PAR(i, M) W.mu[i] = W.mu[i] - mujj * W.tp[i] / sjj;
     for (int j = B.wave; j < M; j += B.nwave) {
         const double vj = W.tp[j];
-        for (int i = B.lane; i < M; i += BLK_LANES) W.Sig[(size_t)j * ld + i] -= W.tp[i] * vj / sjj;
+        if (S.v.epis) for (int i = B.lane; i < M; i += BLK_LANES) W.Sig[(size_t)j * ld + i] -= W.tp[i] / sjj * vj;   // NeFull.c:1606
+        else          for (int i = B.lane; i < M; i += BLK_LANES) W.Sig[(size_t)j * ld + i] -= W.tp[i] * vj / sjj;   // NEmainEff.c:1069
     }
     blk_sync(B);
     if (j1 != last) {
@@ -562,11 +582,10 @@ DEV int bm_inner(const Blk &B, const FoldDev &F, const BmWork &W, int K, double 
         PAR(i, K) W.upos[i] = UP_FREE;
         blk_sync(B);
         double pa = 0, pb = 0, pc = 0, pd = 0;
-        const double r0 = F.rscale[0];
         PAR(h, N) {
             const double tp = -1 + 2 * F.y[h];
             const double lo = log(((tp * 0.9 + 1) / 2) / (1 - (tp * 0.9 + 1) / 2));
-            const double ph = F.X[h] * r0;
+            const double ph = bm_col(F, W, N, 0, h);
             pa += ph; pb += ph * ph; pc += lo; pd += ph * lo;
         }
         const double sa = blk_sum(B, pa), sb = blk_sum(B, pb), sc = blk_sum(B, pc), sd = blk_sum(B, pd);
@@ -598,7 +617,7 @@ DEV int bm_inner(const Blk &B, const FoldDev &F, const BmWork &W, int K, double 
         ll0 = ll;
         double best; int any_del;
         int nu;
-        { PH_BEGIN(); nu = bm_delta_ml(B, W, K, N, S.M - 1, lambda, alpha, &any_del, &best); PH_END(PH_DML); }
+        { PH_BEGIN(); nu = bm_delta_ml(B, W, K, N, S.M - 1, lambda, alpha, S.v.epis, &any_del, &best); PH_END(PH_DML); }
         int worthwhile;
         if (sel == ACT_TERM && !ini_removed && S.M > 2) nu = -1;
         if (nu == -1 && ini_removed) { worthwhile = 0; sel = ACT_TERM; }
@@ -611,7 +630,7 @@ DEV int bm_inner(const Blk &B, const FoldDev &F, const BmWork &W, int K, double 
         } else {
             worthwhile = 1;
             const int act_nu = W.act[nu];
-            double cutoff = best * (act_nu == ACT_ADD ? 0.90 : 1.0);
+            double cutoff = best * (act_nu == ACT_ADD ? S.v.n_add : 1.0);     // NEmainEff.c:422 0.90 | NeFull.c:254 0.99
             if (cutoff < 0.001) cutoff = 0.001;
             n_todo = bm_collect(B, W, K, cutoff);
             if (act_nu == ACT_DEL && n_todo > 1) n_todo = 1;
@@ -636,6 +655,9 @@ DEV int bm_inner(const Blk &B, const FoldDev &F, const BmWork &W, int K, double 
                     bm_reestimate(B, F, W, K, S, jj, newA);
                 } else if (sel == ACT_ADD) {
                     if (S.M + 1 > W.cap) { S.status |= ST_OVERFLOW | ST_ABORT; return 1; }
+                    // NeFull.c:549-553: more bases than the R wrapper's bMax (the reference tests this from the second outer
+                    // iteration on and overruns its arrays in the first; here the fit is stopped either way)
+                    if (S.v.epis && S.M > W.bmax) { S.status |= ST_OVERFLOW | ST_ABORT; return 1; }
                     CNT(c.n_add++; c.sum_m_action += S.M);
                     bm_add(B, F, W, K, S, nu, newA);
                 } else if (sel == ACT_DEL) {
@@ -673,6 +695,7 @@ DEV void bm_fit(const Blk &B, const FoldDev &F, const BmWork &W, int K, double l
                 GmScalars &S, double *loglik)
 {
     S.status = 0; S.M = 2; S.beta = 0; S.b = 0;
+    S.v.n_add = S.v.epis ? 0.99 : 0.90;
     CNT(c = FitCounters{});
     PAR(i, W.ld) W.A[i] = 0;                                   // Calloc'd per fit, never cleared after (Q12)
     blk_sync(B);
@@ -683,7 +706,8 @@ DEV void bm_fit(const Blk &B, const FoldDev &F, const BmWork &W, int K, double l
         vk0 = vk;
         if (bm_inner(B, F, W, K, lambda, alpha, S, iter, &ll)) break;
         double ap = 0;
-        PAR(i, S.M) ap += fabs(W.A[i]);                        // dasum over M = N_used + 1 entries
+        if (S.v.epis) { PAR(i, S.M - 1) ap += W.A[i]; }        // NeFull.c:133-134: the M-1 precisions
+        else { PAR(i, S.M) ap += fabs(W.A[i]); }               // NEmainEff.c:340: dasum over M = N_used + 1 entries (Q12)
         vk = blk_sum(B, ap);
         err = fabs(vk - vk0) / S.M;
     }

@@ -302,10 +302,10 @@ __device__ inline GmWork ws_carve(char *base, int K, int cap, size_t offK, size_
 // binomial workspace: K-vectors, (ld x ld) Sigma and H, ld-vectors, N-vectors, K x ld weighted rows
 struct BmLayout { size_t bytes; int cap, ld, nmax; size_t offK, offSig, offM, offN, offBP; };
 
-static BmLayout bm_layout(int K, int nmax)
+static BmLayout bm_layout(int K, int nmax, int bmax)
 {
     BmLayout L;
-    int cap = K + 1; if (cap > 1024) cap = 1024;
+    int cap = std::min(K, bmax) + 1; if (cap > 1024) cap = 1024;      // model columns incl. the intercept
     L.cap = cap; L.ld = cap + 1; L.nmax = nmax;
     size_t o = 0;
     L.offK = o;   o += align_up((size_t)K * (7 * sizeof(double) + 2 * sizeof(int) + 1), 256);
@@ -335,7 +335,7 @@ __device__ inline BmWork bm_carve(char *base, int K, const BmLayout &L)
     d = (double *)(base + L.offN);
     W.w = d; d += L.nmax; W.pm = d; d += L.nmax; W.yv = d; d += L.nmax; W.e = d; d += L.nmax; W.bphi = d;
     W.BP = (double *)(base + L.offBP);
-    W.cap = L.cap; W.ld = L.ld;
+    W.cap = L.cap; W.ld = L.ld; W.phi_div = 0; W.bmax = L.cap;
     return W;
 }
 
@@ -534,6 +534,7 @@ struct BmCvParams {
     char *ws;
     BmLayout L;
     int K, n_folds, n_units;
+    int epis, bmax;        // epistasis: NeFull.c rule set on the expanded design, at most bmax bases per model
     long long *phase;      // [n_units x PH_N] diagnostic ticks, may be null
 };
 
@@ -543,7 +544,8 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_EU) void bm_cv_kernel(Bm
     __shared__ FitCounters s_cnt;
     __shared__ long long s_ph[PH_N];
     const Blk B = make_blk();
-    const BmWork W = bm_carve(P.ws + (size_t)blockIdx.x * P.L.bytes, P.K, P.L);
+    BmWork W = bm_carve(P.ws + (size_t)blockIdx.x * P.L.bytes, P.K, P.L);
+    W.phi_div = P.epis; W.bmax = P.bmax;
     for (;;) {
         __syncthreads();
         if (threadIdx.x == 0) s_unit = atomicAdd(P.queue, 1);
@@ -555,6 +557,7 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_EU) void bm_cv_kernel(Bm
         const FoldDev F = P.folds[f];
         GmScalars S;
         S.c = &s_cnt; S.ph = s_ph;
+        S.v.epis = P.epis;
 #ifdef PAREBEN_PHASE_TIMERS
         if (threadIdx.x < PH_N) s_ph[threadIdx.x] = 0;
         __syncthreads();
@@ -644,34 +647,59 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_EU) void gm_fit_kernel(F
 struct BmFitParams {
     FoldDev F;
     double lambda, alpha;
-    double *Beta;        // K x 4
+    double *Beta;        // K x 4 (main effects) or bmax x 4 (epistasis: the used bases in model order)
     double *scalars;     // logLikelihood, wald, intercept, Sigma[0,0]
     int *status;
     long long *counters;
     char *ws;
     BmLayout L;
     int K;
+    int epis, p, bmax;   // epistasis: K = p(p+1)/2 columns of the expanded design
 };
 
-// single binomial fit with the reference's .C outputs (ElasticNetBinaryNEmainEff.c:346-389)
+// single binomial fit with the reference's .C outputs: ElasticNetBinaryNEmainEff.c:346-389 (Beta K x 4 indexed by
+// column) or ElasticNetBinaryNeFull.c:154-211 (Beta bMax x 4: the used bases in model order with their loci)
 __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_EU) void bm_fit_kernel(BmFitParams P)
 {
     __shared__ FitCounters s_cnt;
     __shared__ long long s_ph[PH_N];
     const Blk B = make_blk();
-    const BmWork W = bm_carve(P.ws, P.K, P.L);
+    BmWork W = bm_carve(P.ws, P.K, P.L);
+    W.phi_div = P.epis; W.bmax = P.bmax;
     const int K = P.K;
-    PAR(i, K) { P.Beta[i] = i + 1; P.Beta[(size_t)K + i] = i + 1; P.Beta[2 * (size_t)K + i] = 0; P.Beta[3 * (size_t)K + i] = 0; }
+    if (!P.epis) { PAR(i, K) { P.Beta[i] = i + 1; P.Beta[(size_t)K + i] = i + 1; P.Beta[2 * (size_t)K + i] = 0; P.Beta[3 * (size_t)K + i] = 0; } }
+    else { PAR(i, 4 * P.bmax) P.Beta[i] = 0; }
     GmScalars S;
     S.c = &s_cnt; S.ph = s_ph;
+    S.v.epis = P.epis;
     double ll;
     bm_fit(B, P.F, W, K, P.lambda, P.alpha, S, &ll);
     const int M = S.M, ld = W.ld;
-    for (int i = 1 + threadIdx.x; i < M; i += blockDim.x) {
-        const int f = W.used[i - 1];
-        const double sc = P.F.scale[f];
-        P.Beta[2 * (size_t)K + f] = W.mu[i] / sc;
-        P.Beta[3 * (size_t)K + f] = W.Sig[(size_t)i * ld + i] / (sc * sc);
+    if (!P.epis) {
+        for (int i = 1 + threadIdx.x; i < M; i += blockDim.x) {
+            const int f = W.used[i - 1];
+            const double sc = P.F.scale[f];
+            P.Beta[2 * (size_t)K + f] = W.mu[i] / sc;
+            P.Beta[3 * (size_t)K + f] = W.Sig[(size_t)i * ld + i] / (sc * sc);
+        }
+    } else {
+        const int p = P.p, bm = P.bmax;
+        const int meff = M - 1 < bm ? M - 1 : bm;                  // NeFull.c:162-167
+        PAR(i, meff) {
+            const int f = W.used[i];
+            int l1 = f, l2 = f;
+            if (f >= p) {                                          // pair rank -> (i, j), the order of NeFull.c:90-105
+                const long long q = f - p;
+                int a = (int)((2.0 * p - 1.0 - sqrt((2.0 * p - 1.0) * (2.0 * p - 1.0) - 8.0 * (double)q)) * 0.5);
+                while ((long long)(a + 1) * p - (long long)(a + 1) * (a + 2) / 2 <= q) a++;
+                while ((long long)a * p - (long long)a * (a + 1) / 2 > q) a--;
+                l1 = a; l2 = (int)(q - ((long long)a * p - (long long)a * (a + 1) / 2)) + a + 1;
+            }
+            const double sc = P.F.scale[f];
+            P.Beta[i] = l1 + 1; P.Beta[(size_t)bm + i] = l2 + 1;
+            P.Beta[2 * (size_t)bm + i] = W.mu[i + 1] / sc;
+            P.Beta[3 * (size_t)bm + i] = W.Sig[(size_t)(i + 1) * ld + i + 1] / (sc * sc);
+        }
     }
     double part = 0;
     PAR(i, M) {
@@ -884,8 +912,6 @@ extern "C" int pareben_ctx_create(pareben_ctx **out, int device, const double *b
 {
     if (!out || !basis || !target || !fold_id || n < 2 || p < 1 || n_folds < 1) return fail(PAREBEN_EINVAL, "bad argument");
     if (prior != PAREBEN_PRIOR_GAUSSIAN && prior != PAREBEN_PRIOR_BINOMIAL) return fail(PAREBEN_EINVAL, "unknown prior");
-    if (prior == PAREBEN_PRIOR_BINOMIAL && epis != 0)
-        return fail(PAREBEN_EUNSUPPORTED, "binomial + epistasis (ElasticNetBinaryNeFull.c) is not built in this version");
     for (int i = 0; i < n; i++) if (fold_id[i] < 1 || fold_id[i] > n_folds) return fail(PAREBEN_EINVAL, "fold_id out of 1..n_folds");
     std::vector<std::vector<int>> tr(n_folds), te(n_folds);
     for (int f = 0; f < n_folds; f++)
@@ -935,7 +961,7 @@ static int ensure_workspace(pareben_ctx *c, int blocks)
     if (c->prior == PAREBEN_PRIOR_BINOMIAL) {
         int nmax = 1;
         for (auto &f : c->folds) nmax = std::max(nmax, std::max(f.N, f.nte));
-        c->BL = bm_layout(c->kfull, nmax);
+        c->BL = bm_layout(c->kfull, nmax, c->epis ? 2 * c->p : c->kfull);     // NeFull.c: the R wrapper's bMax = 2K bases
         per = c->BL.bytes;
     }
     const size_t need = per * (size_t)blocks;
@@ -1061,7 +1087,8 @@ static int run_enqueue(pareben_ctx *c, int n_cells, const double *alpha, const d
         BmCvParams Q;
         Q.folds = c->d_folds; Q.alpha = D.d_alpha; Q.lambda = D.d_lambda; Q.order = D.d_order; Q.queue = D.d_queue;
         Q.fold_err = D.d_err; Q.status = D.d_status; Q.counters = D.d_cnt; Q.ws = c->d_ws; Q.L = c->BL;
-        Q.K = c->p; Q.n_folds = nF; Q.n_units = n_units; Q.phase = D.d_phase;
+        Q.K = c->kfull; Q.n_folds = nF; Q.n_units = n_units; Q.phase = D.d_phase;
+        Q.epis = c->epis; Q.bmax = 2 * c->p;
         hipLaunchKernelGGL(bm_cv_kernel, dim3(blocks), dim3(FIT_THREADS), LDS_FIT_BYTES, c->stream, Q);
     } else {
         hipLaunchKernelGGL(gm_cv_kernel, dim3(blocks), dim3(FIT_THREADS), LDS_FIT_BYTES, c->stream, P);
@@ -1156,6 +1183,91 @@ extern "C" int pareben_cv_grid(const double *basis, int n, int p, const double *
     rc = pareben_ctx_run(c, n_cells, alpha, lambda, fold_err, status, counters);
     pareben_ctx_destroy(c);
     return rc;
+}
+
+// ------------------------------------------------------------------------------------------
+// The pairwise pass of GetLambdaMax (R/BuildGrid.R:21-30): for every pair i < j the column x_i * x_j, divided by
+// its norm, is correlated with the centred (NOT normalised) target; the result is the largest such
+// value.  O(n K^2) -- an interpreted double loop in the reference, the dominant cost of building an Epis grid there.
+// One wavefront per pair, lanes over samples (both columns are contiguous: coalesced), two passes over the pair
+// column (its squared norm, then the correlation of the normalised column: the same operations per element as the
+// R expressions, summed in a fixed lane-strided + butterfly order), block maximum, then one compare-and-swap
+// maximum per block on the result word.  A pair column that is identically zero gives 0/0 = NaN, which -- as in
+// R's `if (corBy > lambda_Max)` -- never wins.
+__global__ __launch_bounds__(256) void pair_lambda_kernel(const double *__restrict__ X, int N, int K,
+                                                          const double *__restrict__ centred, long long n_pairs,
+                                                          unsigned long long *__restrict__ best)
+{
+    extern __shared__ double lc[];                                // centred target (when it fits; else read from memory)
+    __shared__ double wmax[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool in_lds = N <= 8192;
+    if (in_lds) for (int h = threadIdx.x; h < N; h += blockDim.x) lc[h] = centred[h];
+    __syncthreads();
+    double mine = -INFINITY;
+    for (long long q = (long long)blockIdx.x * 4 + wave; q < n_pairs; q += (long long)gridDim.x * 4) {
+        int i = (int)((2.0 * K - 1.0 - sqrt((2.0 * K - 1.0) * (2.0 * K - 1.0) - 8.0 * (double)q)) * 0.5);
+        while ((long long)(i + 1) * K - (long long)(i + 1) * (i + 2) / 2 <= q) i++;
+        while ((long long)i * K - (long long)i * (i + 1) / 2 > q) i--;
+        const int j = (int)(q - ((long long)i * K - (long long)i * (i + 1) / 2)) + i + 1;
+        const double *xi = X + (size_t)i * N, *xj = X + (size_t)j * N;
+        double s2 = 0;
+        for (int h = lane; h < N; h += 64) { const double z = xi[h] * xj[h]; s2 += z * z; }
+        for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+        const double nrm = sqrt(s2);
+        double d = 0;
+        for (int h = lane; h < N; h += 64) { const double z = xi[h] * xj[h]; d += (z / nrm) * (in_lds ? lc[h] : centred[h]); }
+        for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+        if (d > mine) mine = d;                                   // NaN never compares greater
+    }
+    if (lane == 0) wmax[wave] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double m = wmax[0];
+        for (int w = 1; w < 4; w++) if (wmax[w] > m) m = wmax[w];
+        unsigned long long cur = *best;                           // compare-and-swap maximum on the double's bits
+        while (m > __longlong_as_double((long long)cur)) {
+            const unsigned long long seen = atomicCAS(best, cur, (unsigned long long)__double_as_longlong(m));
+            if (seen == cur) break;
+            cur = seen;
+        }
+    }
+}
+
+extern "C" int pareben_lambda_max_pairs(const double *basis, int n, int p, const double *target, int device, double *out)
+{
+    if (!basis || !target || !out || n < 1 || p < 1) return fail(PAREBEN_EINVAL, "bad argument");
+    *out = -INFINITY;
+    if (p < 2) return PAREBEN_OK;
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(PAREBEN_EINVAL, "no such device");
+    HIPCHK(hipSetDevice(device));
+    long double ms = 0;                                           // Target - mean(Target); R's mean(): long double sum / n, then one refinement pass
+    for (int i = 0; i < n; i++) ms += target[i];
+    ms /= n;
+    { long double r = 0; for (int i = 0; i < n; i++) r += target[i] - ms; ms += r / n; }
+    const double mean = (double)ms;
+    std::vector<double> c(n);
+    for (int i = 0; i < n; i++) c[i] = target[i] - mean;
+    double *d_x = nullptr, *d_c = nullptr; unsigned long long *d_best = nullptr;
+    auto cleanup = [&]() { hipFree(d_x); hipFree(d_c); hipFree(d_best); };
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(e_ == hipErrorOutOfMemory ? PAREBEN_ENOMEM : PAREBEN_EHIP, #x, e_); } } while (0)
+    CK(dmalloc(&d_x, (size_t)n * p)); CK(dmalloc(&d_c, (size_t)n)); CK(dmalloc(&d_best, (size_t)1));
+    CK(hipMemcpy(d_x, basis, sizeof(double) * (size_t)n * p, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_c, c.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+    const double ninf = -INFINITY;
+    CK(hipMemcpy(d_best, &ninf, sizeof(double), hipMemcpyHostToDevice));
+    const long long n_pairs = (long long)p * (p - 1) / 2;
+    const int blocks = (int)std::min<long long>((n_pairs + 3) / 4, 256LL * 64);
+    const size_t lds = n <= 8192 ? sizeof(double) * (size_t)n : 0;
+    hipLaunchKernelGGL(pair_lambda_kernel, dim3(blocks), dim3(256), lds, 0, d_x, n, p, d_c, n_pairs, d_best);
+    CK(hipGetLastError());
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(out, d_best, sizeof(double), hipMemcpyDeviceToHost));
+#undef CK
+    cleanup();
+    return PAREBEN_OK;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1326,8 +1438,8 @@ static int fit_one(int prior, int epis, const double *basis, const double *targe
     if (rc) return bail(rc);
     rc = ensure_workspace(c, 1);
     if (rc) return bail(rc);
-    const size_t KF = (size_t)c->kfull;
-    const int ncol = epis ? 5 : 4;
+    const int ncol = (epis && prior == PAREBEN_PRIOR_GAUSSIAN) ? 5 : 4;
+    const size_t KF = (epis && prior == PAREBEN_PRIOR_BINOMIAL) ? (size_t)2 * k : (size_t)c->kfull;     // rows of the Beta table
     double *d_beta = nullptr, *d_sc = nullptr; int *d_st = nullptr; long long *d_cnt = nullptr;
     auto cleanup = [&]() { hipFree(d_beta); hipFree(d_sc); hipFree(d_st); hipFree(d_cnt); };
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return bail(fail(PAREBEN_EHIP, #x, e_)); } } while (0)
@@ -1346,7 +1458,7 @@ static int fit_one(int prior, int epis, const double *basis, const double *targe
     } else {
         BmFitParams P;
         P.F = F; P.lambda = lambda; P.alpha = alpha; P.Beta = d_beta; P.scalars = d_sc; P.status = d_st; P.counters = d_cnt;
-        P.ws = c->d_ws; P.L = c->BL; P.K = k;
+        P.ws = c->d_ws; P.L = c->BL; P.K = c->kfull; P.epis = epis; P.p = k; P.bmax = 2 * k;
         CK(hipFuncSetAttribute((const void *)bm_fit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FIT_BYTES));
         hipLaunchKernelGGL(bm_fit_kernel, dim3(1), dim3(FIT_THREADS), LDS_FIT_BYTES, c->stream, P);
     }
@@ -1397,6 +1509,20 @@ extern "C" int pareben_fit_binomial(const double *basis, const double *target, d
     if (!basis || !target || !Beta || !wald || !intercept || !logLikelihood || n < 2 || k < 1) return fail(PAREBEN_EINVAL, "bad argument");
     double sc[4];
     const int rc = fit_one(PAREBEN_PRIOR_BINOMIAL, 0, basis, target, lambda, alpha, n, k, device, Beta, sc, 4, counters);
+    if (rc == PAREBEN_OK) { *logLikelihood = sc[0]; *wald = sc[1]; intercept[0] = sc[2]; intercept[1] = sc[3]; }
+    return rc;
+}
+
+extern "C" int pareben_fit_binomial_epis(const double *basis, const double *target, double lambda, double alpha,
+                                         double *logLikelihood, double *Beta, double *wald, double *intercept,
+                                         int n, int k, int verbose, int bMax, int device, int64_t *counters)
+{
+    (void)verbose;
+    if (!basis || !target || !Beta || !wald || !intercept || !logLikelihood || n < 2 || k < 2) return fail(PAREBEN_EINVAL, "bad argument");
+    if (bMax != 2 * k) return fail(PAREBEN_EINVAL, "bMax must be 2*k, what EBelasticNet.Binomial passes (Beta is bMax x 4)");
+    if ((long long)k * (k + 1) / 2 > 2000000000LL) return fail(PAREBEN_EINVAL, "too many pairwise columns");
+    double sc[4];
+    const int rc = fit_one(PAREBEN_PRIOR_BINOMIAL, 1, basis, target, lambda, alpha, n, k, device, Beta, sc, 4, counters);
     if (rc == PAREBEN_OK) { *logLikelihood = sc[0]; *wald = sc[1]; intercept[0] = sc[2]; intercept[1] = sc[3]; }
     return rc;
 }

@@ -28,13 +28,14 @@ struct FoldDev {
 // The two Gaussian reference kernels share their skeleton; these are the constants and rules in
 // which elasticNetLinearNeFull2.c (epis = 1) differs from elasticNetLinearNeMainEff.c (epis = 0).
 struct GmVariant {
-    int epis;           // selects the priority / initial-beta rules
-    double n_add;       // block cut-off factor        MainEff.c:275  0.9   | Full2.c:293  0.99
-    double ml_delta;    // minimum dML                 MainEff.c:277  1e-3  | Full2.c:295  1e-2
-    double reest_tol;   // |dlog alpha| termination    MainEff.c:543  1e-3  | Full2.c:558  0.1
-    double alpha_max;   // initial precision clamp     MainEff.c:995  1e2   | Full2.c:849  1e3
-    double b_eps;       // intercept denominator guard MainEff.c:188  1e-10 | Full2.c:202  none
+    int epis = 0;              // selects the priority / initial-beta rules
+    double n_add = 0.9;        // block cut-off factor        MainEff.c:275  0.9   | Full2.c:293  0.99
+    double ml_delta = 1e-3;    // minimum dML                 MainEff.c:277  1e-3  | Full2.c:295  1e-2
+    double reest_tol = 1e-3;   // |dlog alpha| termination    MainEff.c:543  1e-3  | Full2.c:558  0.1
+    double alpha_max = 1e2;    // initial precision clamp     MainEff.c:995  1e2   | Full2.c:849  1e3
+    double b_eps = 1e-10;      // intercept denominator guard MainEff.c:188  1e-10 | Full2.c:202  none
 };
+// The binomial kernels (bm_fit.h) read only `epis` (main effects: NEmainEff.c rules, epistasis: NeFull.c rules) and set n_add themselves.
 
 // Per-fit event counters (SURVEY.md 8(d) accounting).
 struct FitCounters {

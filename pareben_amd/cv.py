@@ -43,7 +43,7 @@ def CrossValidate(BASIS, Target, nFolds, foldId=0, Epis="no", prior="gaussian", 
         raise ValueError('prior must be "gaussian" or "binomial"')
     X = np.asarray(BASIS, dtype=np.float64)
     y = np.asarray(Target, dtype=np.float64).reshape(-1)
-    alpha, lam = BuildGrid(X, y, nFolds, Epis, nAlpha=nAlpha, nLambda=nLambda)
+    alpha, lam = BuildGrid(X, y, nFolds, Epis, nAlpha=nAlpha, nLambda=nLambda, device=device)
     folds = AssignToFolds(X, nFolds, foldId, sample_kind=sample_kind)
     n_cells = len(alpha)
 

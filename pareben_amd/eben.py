@@ -108,11 +108,10 @@ def Gaussian(BASIS, Target, lambda_, alpha, Epis="no", verbose=0, device=0):
 def Binomial(BASIS, Target, lambda_, alpha, Epis="no", verbose=0, device=0):
     """EBelasticNet.Binomial(BASIS, Target, lambda, alpha, Epis = "no", verbose = 0) ->
     dict(weight M x 6, logLikelihood, WaldScore, Intercept[2], lambda, alpha)."""
-    if Epis == "yes":
-        raise _lib.ParebenError("binomial + epistasis (ElasticNetBinaryNEfull) is not built in this version")
     X = np.asarray(BASIS, dtype=np.float64)
-    r = _lib.fit_binomial(X, Target, lambda_, alpha, device=device)
-    weight = _weight_table(r["Beta"], 2, X.shape[0], False)
+    epis = Epis == "yes"
+    r = _lib.fit_binomial(X, Target, lambda_, alpha, device=device, epis=epis)
+    weight = _weight_table(r["Beta"], 2, X.shape[0], epis)      # :47-67: rows with a non-zero effect; Epis: mains then pairs, each by locus1
     return {"weight": weight, "logLikelihood": r["logLikelihood"], "WaldScore": r["wald"], "Intercept": r["intercept"],
             "lambda": lambda_, "alpha": alpha}
 

@@ -23,12 +23,29 @@ def _as_matrix(BASIS):
     return X
 
 
-def GetLambdaMax(BASIS, Target, Epis="no"):
+def _pairs_host(X, centred):
+    """The pairwise pass of GetLambdaMax on the host (numpy): the checker of the device pass, and what
+    ``GetLambdaMax(..., device=None)`` uses."""
+    K = X.shape[1]
+    best = -math.inf
+    for i in range(K - 1):
+        prod = X[:, i:i + 1] * X[:, i + 1:]
+        nrm = np.sqrt(np.sum(prod * prod, axis=0))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            c2 = (prod / nrm).T @ centred
+        for c in c2:
+            if c > best:
+                best = float(c)
+    return best
+
+
+def GetLambdaMax(BASIS, Target, Epis="no", device=None):
     """R/BuildGrid.R:5-32.  max(log 1.1, max_j x_j.response/|x_j|); with Epis="yes" also all
-    pairs x_i*x_j, correlated with the centred but *un-normalised* target."""
+    pairs x_i*x_j, correlated with the centred but *un-normalised* target.
+    The O(n K^2) pairwise pass runs on GPU `device` (pareben_lambda_max_pairs) when one is given -- what
+    CrossValidate does -- and in numpy otherwise."""
     X = _as_matrix(BASIS)
     yv = np.asarray(Target, dtype=np.float64).reshape(-1)
-    K = X.shape[1]
     lam = math.log(1.1)
     centred = yv - yv.mean()
     response = centred / math.sqrt(float(np.sum(centred * centred)))
@@ -39,24 +56,23 @@ def GetLambdaMax(BASIS, Target, Epis="no"):
         if c > lam:
             lam = float(c)
     if Epis == "yes":
-        for i in range(K - 1):
-            prod = X[:, i:i + 1] * X[:, i + 1:]
-            nrm = np.sqrt(np.sum(prod * prod, axis=0))
-            with np.errstate(divide="ignore", invalid="ignore"):
-                c2 = (prod / nrm).T @ centred
-            for c in c2:
-                if c > lam:
-                    lam = float(c)
+        if device is None:
+            pair = _pairs_host(X, centred)
+        else:
+            from . import _lib
+            pair = _lib.lambda_max_pairs(X, yv, device=device)
+        if pair > lam:
+            lam = float(pair)
     return lam
 
 
-def BuildGrid(BASIS, Target, nFolds, Epis="no", nAlpha=20, nLambda=20):
+def BuildGrid(BASIS, Target, nFolds, Epis="no", nAlpha=20, nLambda=20, device=None):
     """R/BuildGrid.R:34-52.  Returns (alpha, lambda) arrays of the expanded grid, alpha fastest
     (``expand.grid(alpha = Alpha, lambda = Lambda)``).  nAlpha/nLambda default to the reference's
     hard-wired 20 x 20; other sizes are an extension: lambda keeps the
     10*lambda_max ... 0.001*10*lambda_max log range split in nLambda-1 steps, alpha is
     seq(1, by = -1/nAlpha)."""
-    lambda_max = GetLambdaMax(BASIS, Target, Epis) * 10
+    lambda_max = GetLambdaMax(BASIS, Target, Epis, device=device) * 10
     lambda_min = math.log(0.001 * lambda_max)
     step = (math.log(lambda_max) - lambda_min) / (nLambda - 1)
     Lambda = np.exp(r_seq_by(math.log(lambda_max), lambda_min, -step))

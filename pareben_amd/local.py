@@ -64,7 +64,7 @@ def LocalSearch(BASIS, Target, nFolds, Epis="no", foldId=0, prior="gaussian", de
         raise ValueError("For the binomial prior, please use the global search.")
     X = np.asarray(BASIS, dtype=np.float64)
     y = np.asarray(Target, dtype=np.float64).reshape(-1)
-    alpha, lam = BuildGrid(X, y, nFolds, Epis)                   # same lambda / alpha values as :21-50
+    alpha, lam = BuildGrid(X, y, nFolds, Epis, device=device)    # same lambda / alpha values as :21-50
     folds = AssignToFolds(X, nFolds, foldId, sample_kind=sample_kind)
     with _lib.Context(X, y, folds, nFolds, prior="gaussian", epis=(Epis == "yes"), device=device) as ctx:
         fold_err, status, _ = ctx.run(alpha, lam)

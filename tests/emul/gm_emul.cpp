@@ -185,15 +185,30 @@ extern "C" int emul_gm_fit(const double *X, const double *y, int n, int p, doubl
 }
 
 
-// same contract as pareben_cv_grid (binomial, main effects): fold_err = mean held-out log-likelihood
-extern "C" int emul_bm_cv_grid(const double *basis, int n, int p, const double *y, const int *fold_id, int n_folds,
-                               const double *alpha, const double *lambda, int n_cells,
-                               double *fold_err, int *status, long long *counters)
+// same contract as pareben_cv_grid (binomial; epis = 1: the NeFull.c rule set on the expanded design): fold_err = mean
+// held-out log-likelihood
+static int bm_cv_impl(const double *basis_in, int n, int p_in, const double *y, const int *fold_id, int n_folds,
+                      const double *alpha, const double *lambda, int n_cells, int epis,
+                      double *fold_err, int *status, long long *counters)
 {
+    std::vector<double> Z;
+    const double *basis = basis_in;
+    int p = p_in;
+    if (epis) {                                    // expanded design, reference column order (NeFull.c:90-105)
+        p = p_in * (p_in + 1) / 2;
+        Z.resize((size_t)n * p);
+        std::memcpy(Z.data(), basis_in, sizeof(double) * (size_t)n * p_in);
+        size_t kk = p_in;
+        for (int i = 0; i < p_in - 1; i++)
+            for (int j = i + 1; j < p_in; j++, kk++)
+                for (int h = 0; h < n; h++) Z[kk * n + h] = basis_in[(size_t)i * n + h] * basis_in[(size_t)j * n + h];
+        basis = Z.data();
+    }
     std::vector<Fold> folds(n_folds);
     int nmax = 1;
     for (int f = 0; f < n_folds; f++) { prepare(folds[f], basis, n, p, y, fold_id, f); nmax = std::max(nmax, std::max(folds[f].N, folds[f].nte)); }
-    int cap = p + 1; if (cap > 1024) cap = 1024;
+    const int bmax = epis ? 2 * p_in : p;
+    int cap = std::min(p, bmax) + 1; if (cap > 1024) cap = 1024;
     const int ld = cap + 1;
     std::vector<double> kd((size_t)7 * p), sig((size_t)2 * ld * ld), md((size_t)9 * ld), nd((size_t)5 * nmax), bp((size_t)p * ld);
     std::vector<int> ki((size_t)2 * p), used(ld); std::vector<signed char> act(p);
@@ -207,12 +222,12 @@ extern "C" int emul_bm_cv_grid(const double *basis, int n, int p, const double *
     W.used = used.data();
     d = nd.data();
     W.w = d; d += nmax; W.pm = d; d += nmax; W.yv = d; d += nmax; W.e = d; d += nmax; W.bphi = d;
-    W.BP = bp.data(); W.cap = cap; W.ld = ld;
+    W.BP = bp.data(); W.cap = cap; W.ld = ld; W.phi_div = epis; W.bmax = bmax;
     Blk B; B.tid = 0; B.nthr = 1; B.lane = 0; B.wave = 0; B.nwave = 1; B.red = nullptr; B.ired = nullptr; B.pool = nullptr; B.pool_n = 0;
     for (int c = 0; c < n_cells; c++)
         for (int f = 0; f < n_folds; f++) {
             FoldDev F = dev_view(folds[f]);
-            GmScalars S; FitCounters cnt; S.c = &cnt; S.ph = nullptr;
+            GmScalars S; FitCounters cnt; S.c = &cnt; S.ph = nullptr; S.v.epis = epis;
             double ll;
             bm_fit(B, F, W, p, lambda[c], alpha[c], S, &ll);
             const int u = c * n_folds + f;
@@ -221,4 +236,18 @@ extern "C" int emul_bm_cv_grid(const double *basis, int n, int p, const double *
             if (counters) std::memcpy(counters + (size_t)u * PAREBEN_NCOUNTERS, &cnt, sizeof cnt);
         }
     return 0;
+}
+
+extern "C" int emul_bm_cv_grid(const double *basis, int n, int p, const double *y, const int *fold_id, int n_folds,
+                               const double *alpha, const double *lambda, int n_cells,
+                               double *fold_err, int *status, long long *counters)
+{
+    return bm_cv_impl(basis, n, p, y, fold_id, n_folds, alpha, lambda, n_cells, 0, fold_err, status, counters);
+}
+
+extern "C" int emul_bf_cv_grid(const double *basis, int n, int p, const double *y, const int *fold_id, int n_folds,
+                               const double *alpha, const double *lambda, int n_cells,
+                               double *fold_err, int *status, long long *counters)
+{
+    return bm_cv_impl(basis, n, p, y, fold_id, n_folds, alpha, lambda, n_cells, 1, fold_err, status, counters);
 }

@@ -35,6 +35,7 @@ def lib():
         _LIB.eben_gm_fit.argtypes = [dp, dp, C.c_int, C.c_int, C.c_double, C.c_double, dp, dp, dp, dp, C.POINTER(Counters)]
         _LIB.eben_gf_fit.argtypes = _LIB.eben_gm_fit.argtypes
         _LIB.eben_bm_fit.argtypes = [dp, dp, C.c_int, C.c_int, C.c_double, C.c_double, dp, dp, dp, dp, C.POINTER(Counters)]
+        _LIB.eben_bf_fit.argtypes = [dp, dp, C.c_int, C.c_int, C.c_double, C.c_double, dp, dp, C.c_int, dp, dp, C.POINTER(Counters)]
         _LIB.eben_cv_grid.argtypes = [dp, C.c_int, C.c_int, dp, ip, C.c_int, dp, dp, C.c_int, C.c_int, C.c_int, C.c_int, dp, C.POINTER(Counters)]
     return _LIB
 
@@ -64,15 +65,20 @@ def fit_gaussian(X, y, lam, alpha, epis=False):
     return dict(Beta=Beta, wald=wald.value, intercept=icpt.value, residual=resid.value, counters=cnt.asdict(), rc=rc)
 
 
-def fit_binomial(X, y, lam, alpha):
+def fit_binomial(X, y, lam, alpha, epis=False):
+    """epis=False: Beta K x 4 (ElasticNetBinaryNEmainEff); epis=True: Beta 2K x 4 = the used bases in model order
+    (ElasticNetBinaryNEfull with the R wrapper's bMax = 2K)."""
     X = np.asfortranarray(X, dtype=np.float64)
     y = np.ascontiguousarray(y, dtype=np.float64).reshape(-1)
     N, K = X.shape
-    Beta = np.zeros((K, 4), order="F")
+    Beta = np.zeros((2 * K if epis else K, 4), order="F")
     ll, wald = C.c_double(0), C.c_double(0)
     icpt = np.zeros(2)
     cnt = Counters()
-    rc = lib().eben_bm_fit(_dp(X), _dp(y), N, K, float(lam), float(alpha), C.byref(ll), _dp(Beta), C.byref(wald), _dp(icpt), C.byref(cnt))
+    if epis:
+        rc = lib().eben_bf_fit(_dp(X), _dp(y), N, K, float(lam), float(alpha), C.byref(ll), _dp(Beta), 2 * K, C.byref(wald), _dp(icpt), C.byref(cnt))
+    else:
+        rc = lib().eben_bm_fit(_dp(X), _dp(y), N, K, float(lam), float(alpha), C.byref(ll), _dp(Beta), C.byref(wald), _dp(icpt), C.byref(cnt))
     return dict(Beta=Beta, loglik=ll.value, wald=wald.value, intercept=icpt, counters=cnt.asdict(), rc=rc)
 
 

@@ -5,6 +5,7 @@ quirk without a GPU; the parallel execution itself is covered by the -m gpu test
 import numpy as np
 
 import emul_lib
+from pareben_amd.grid import BuildGrid, AssignToFolds
 
 NAMES = ("n_outer", "n_inner", "n_add", "n_del", "n_reest", "n_fullstat", "sum_m_action",
          "sum_m_full", "sum_m2_full", "m_final")
@@ -41,6 +42,22 @@ def test_binomial_subgrid(golden):
                                   prior="binomial")
     assert np.abs(E - g["fold_err"][sel]).max() < 1e-12
     assert np.all(st == 0)
+
+
+def test_binomial_epistasis_subgrid(golden, oracle):
+    """Bf: the binomial device source with the NeFull.c rule set on the expanded design (CPU build) against the
+    oracle, which keeps the reference's implicit pair columns and its association of the products -- two
+    restatements that share no code.  BASISbinomial is {-1, 0, 1}-coded, so the products are exact either way."""
+    X, y = golden.BASISbinomial[::2, :30][:200], golden.yBinomial[::2][:200]
+    fid = AssignToFolds(X, 3)
+    alpha, lam = BuildGrid(X, y, 3)
+    sel = np.arange(0, 400, 27)
+    Eo, co, rc = oracle.cv_grid(X, y, fid, 3, alpha[sel], lam[sel], prior="binomial", epis=True, n_threads=8)
+    E, st, cnt = emul_lib.cv_grid(X, y, fid, 3, alpha[sel], lam[sel], prior="binomial", epis=True)
+    assert rc == 0 and np.all(st == 0)
+    assert np.abs(E - Eo).max() < 1e-8
+    assert cnt[..., 2].sum() == co["n_add"] and cnt[..., 3].sum() == co["n_del"] and cnt[..., 4].sum() == co["n_reest"]
+    assert cnt[..., 10].max() == co["m_max"] and co["m_max"] > 20
 
 
 def test_epistasis_subgrid(golden):

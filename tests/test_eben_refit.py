@@ -100,5 +100,28 @@ def test_binomial_refit_vs_oracle(golden, oracle):
         assert abs(r["logLikelihood"] - o["loglik"]) < 1e-8 * abs(o["loglik"])
         assert abs(r["WaldScore"] - o["wald"]) < 1e-7 * abs(o["wald"])
         assert np.allclose(r["Intercept"], o["intercept"], rtol=1e-8)
-    with pytest.raises(pareben_amd.ParebenError):
-        pareben_amd.EBelasticNet.Binomial(X, y, lam[150], alpha[150], Epis="yes")
+
+
+@pytest.mark.gpu
+def test_binomial_epistasis_refit_vs_oracle(golden, oracle):
+    """EBelasticNet.Binomial(Epis = "yes"): pareben_fit_binomial_epis' raw table (2K x 4, used bases in model order,
+    ElasticNetBinaryNeFull.c:154-211) and the weight table of EBelasticNet.Binomial.R:47-78 (mains then pairs, each
+    ordered by locus1, t and p columns) against the oracle."""
+    X, y = golden.BASISbinomial[::2, :30][:200], golden.yBinomial[::2][:200]
+    alpha, lam = BuildGrid(X, y, 3)
+    for c in (150, 399):
+        raw = pareben_amd.fit_binomial(X, y, lam[c], alpha[c], epis=True)
+        o = oracle.fit_binomial(X, y, lam[c], alpha[c], epis=True)
+        m = o["counters"]["m_final"]
+        assert o["rc"] == 0 and raw["counters"]["m_final"] == m
+        assert np.array_equal(raw["Beta"][:, :2], o["Beta"][:, :2]) and np.all(raw["Beta"][m:] == 0)
+        assert np.allclose(raw["Beta"][:m, 2:], o["Beta"][:m, 2:], rtol=1e-7, atol=0)
+        assert abs(raw["logLikelihood"] - o["loglik"]) < 1e-8 * abs(o["loglik"])
+        assert abs(raw["wald"] - o["wald"]) < 1e-7 * abs(o["wald"])
+        assert np.allclose(raw["intercept"], o["intercept"], rtol=1e-8)
+        r = pareben_amd.EBelasticNet.Binomial(X, y, lam[c], alpha[c], Epis="yes")
+        w = r["weight"]
+        assert w.shape == (m, 6)
+        main = w[w[:, 0] == w[:, 1]]; pair = w[w[:, 0] != w[:, 1]]
+        assert np.array_equal(w, np.vstack([main, pair])) and np.all(np.diff(main[:, 0]) >= 0) and np.all(np.diff(pair[:, 0]) >= 0)
+        assert np.allclose(w[:, 4], np.abs(w[:, 2]) / (np.sqrt(w[:, 3]) + 1e-20))

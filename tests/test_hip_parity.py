@@ -4,6 +4,8 @@ against the oracle on the same inputs and against the committed golden fixtures.
 Bar (BASELINE.json north_star): cv.error within 1e-6 (relative), selected (alpha, lambda) exact.
 Tolerances used here are tighter where the data allow: fold SSE 1e-9 relative, identical event
 counters (= identical add/delete/re-estimate sequence) on the bundled data."""
+import os
+
 import numpy as np
 import pytest
 
@@ -192,8 +194,8 @@ def test_edge_cases(oracle):
     # argument errors surface as exceptions, not crashes
     with pytest.raises(pareben_amd.ParebenError):
         pareben_amd.Context(X, y, np.zeros(41, dtype=np.int32), 2)
-    with pytest.raises(pareben_amd.ParebenError):
-        pareben_amd.Context(X, y, fid, 2, prior="binomial", epis=True)   # Bf (binomial + epistasis) is not built
+    with pytest.raises(ValueError):
+        pareben_amd.Context(X, y, fid, 2, prior="poisson")
 
 
 @pytest.mark.parametrize("n,p,nf", [(1000, 2000, 5)])
@@ -252,6 +254,34 @@ def test_binomial_synthetic_vs_oracle(oracle):
     assert rc == 0 and np.all(st & 8 == 0)
     assert np.abs(E - Eo).max() < 1e-8
     assert cnt[..., 2].sum() == co["n_add"] and cnt[..., 3].sum() == co["n_del"]
+
+
+def test_binomial_epistasis_vs_oracle(golden, oracle):
+    """Bf through the C ABI: CrossValidate(prior = "binomial", Epis = "yes") -- the grid with the pairwise pass of
+    GetLambdaMax, the NeFull.c rule set on the expanded design, held-out log-likelihood with pair columns -- against
+    the oracle (implicit pair columns, the reference's association).  Oracle parity for Bf is unpinned (no
+    reference-held output); the two sides share no code."""
+    X, y = golden.BASISbinomial[::2, :30][:200], golden.yBinomial[::2][:200]
+    fid = AssignToFolds(X, 3)
+    alpha, lam = BuildGrid(X, y, 3)                              # a grid that reaches active sets of ~25 bases
+    sel = np.arange(0, 400, 9)
+    with pareben_amd.Context(X, y, fid, 3, prior="binomial", epis=True) as ctx:
+        E, st, cnt = ctx.run(alpha[sel], lam[sel])
+    Eo, co, rc = oracle.cv_grid(X, y, fid, 3, alpha[sel], lam[sel], prior="binomial", epis=True, n_threads=8)
+    assert rc == 0 and np.all(st & 8 == 0)
+    assert np.abs(E - Eo).max() < 1e-8
+    assert cnt[..., 2].sum() == co["n_add"] and cnt[..., 3].sum() == co["n_del"] and cnt[..., 4].sum() == co["n_reest"]
+    assert cnt[..., 10].max() == co["m_max"] and co["m_max"] > 20
+    out = pareben_amd.CrossValidate(X, y, nFolds=3, Epis="yes", prior="binomial", search="global", return_stats=True)
+    D = out["Results.Detail"]
+    a2, l2 = np.asarray(D["alpha"])[::3], np.asarray(D["lambda"])[::3]
+    E2 = np.asarray(D["logL"]).reshape(400, 3)
+    pick = np.arange(0, 400, 37)
+    Eo2, _, rc2 = oracle.cv_grid(X, y, fid, 3, a2[pick], l2[pick], prior="binomial", epis=True, n_threads=8)
+    assert rc2 == 0 and np.abs(E2[pick] - Eo2).max() < 1e-8
+    S = out["Results.Summary"]
+    i = int(np.argmin(np.asarray(S["Likelihood"])))
+    assert out["alpha.optimal"] == np.asarray(S["alpha"])[i] and out["lambda.optimal"] == np.asarray(S["lambda"])[i]
 
 
 def test_epistasis_vs_golden(golden):
@@ -463,6 +493,28 @@ def test_config2_cells_vs_oracle_fixture():
     tot = cnt.sum(axis=(0, 1))
     for j, n in enumerate(("n_outer", "n_inner", "n_add", "n_del", "n_reest", "n_fullstat")):
         assert tot[j] == want[n], n
+
+
+def test_lambda_max_pair_pass_on_device(golden, yeast):
+    """pareben_lambda_max_pairs (R/BuildGrid.R:21-30 on the GPU) against the numpy restatement of the same R
+    expressions: bundled BASIS (with an all-zero pair column: 0/0 never wins), a Gaussian design with ragged n, and the
+    paper's Epis size (yeast n = 200, k = 300: 44 850 pairs).  BuildGrid(device=...) then yields the same grid."""
+    from pareben_amd.grid import _pairs_host, GetLambdaMax
+    cases = [(golden.BASIS[:200, :60], golden.y[:200])]
+    rng = np.random.default_rng(4)
+    Xg = rng.standard_normal((157, 41)); Xg[:, 3] = 0.0
+    cases.append((Xg, rng.standard_normal(157) * 3 + 1))
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "yeast_timing_200x600.npz"))
+    B = np.unpackbits(d["bits"], axis=0)[:int(d["n"])].astype(np.float64) * 2.0 - 1.0
+    cases.append((B[:, :300], d["y"].astype(np.float64)))
+    for X, y in cases:
+        host = _pairs_host(np.asarray(X, dtype=np.float64), y - y.mean())
+        dev = pareben_amd._lib.lambda_max_pairs(X, y)
+        assert abs(dev - host) <= 1e-12 * abs(host), (dev, host)
+        a1, l1 = BuildGrid(X, y, 5, "yes")
+        a2, l2 = BuildGrid(X, y, 5, "yes", device=0)
+        assert np.array_equal(a1, a2) and np.allclose(l1, l2, rtol=1e-12, atol=0)
+    assert pareben_amd._lib.lambda_max_pairs(golden.BASIS[:50, :1], golden.y[:50]) == -np.inf
 
 
 def test_multi_gpu_entry_through_rccl(golden):
