@@ -337,6 +337,8 @@ def main():
                        "setup_s": {"build_grid_and_folds": t_grid, "ctx_create": t_ctx, "first_run": t_first},
                        "alpha_opt": state["best"][0], "lambda_opt": state["best"][1], "cv_error": state["best"][2],
                        "aborted_fits": int(np.sum(st & 8 != 0)), "fits_past_reference_basisMax": int(np.sum(st & 1 != 0)),
+                       "status_histogram": {str(int(k)): int(v) for k, v in zip(*np.unique(st, return_counts=True))},
+                       "active_set_max": int(state["cnt"][..., 10].max()),
                        "launch": launch, "kernel_ms": tim},
             "roofline": roof,
         }

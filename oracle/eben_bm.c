@@ -15,7 +15,8 @@
  *   the R wrapper (EBelasticNet.Binomial.R:7-9), checked as N_used+1 > bMax (:549-553); output = the used
  *   bases in model order, bMax x 4 (:154-211).
  *
- * TEST INFRASTRUCTURE ONLY (see eben_oracle.h).  Own data structures (state struct, 0-based
+ * TEST INFRASTRUCTURE ONLY (see eben_oracle.h).  PARITY UNPINNED: no reference-held output of a binomial fit exists
+ * to check this file against (eben_oracle.h, "Pinning").  Own data structures (state struct, 0-based
  * feature ids), the reference's arithmetic order (sequential sums, -ffp-contract=off) and its
  * quirks: Q1 first basis is column 0; Q12 the outer stopping sum reads one slot past the active
  * precisions; Q15 add-priority never fires; the re-estimate S/Q update reads the already

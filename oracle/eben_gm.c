@@ -6,7 +6,9 @@
  * each cited where the variant is consulted.  Gf runs on the explicitly expanded design
  * [x_1..x_K, x_1*x_2, x_1*x_3, ..] (the reference regenerates those columns on the fly).
  *
- * TEST INFRASTRUCTURE ONLY (see eben_oracle.h).  Written from the algorithm, with its own
+ * TEST INFRASTRUCTURE ONLY (see eben_oracle.h).  Pinning: the Gm rule set reproduces the authors' stored real-R
+ * run to 1e-15 (tests/test_oracle_golden.py::test_oracle_reproduces_real_r_fit); the Gf rule set is PARITY
+ * UNPINNED (no reference-held epistasis output).  Written from the algorithm, with its own
  * data structures (one dense row-major arena for the feature x basis cache instead of row
  * pointers, 0-based indices, a state struct), keeping the reference's arithmetic order
  * (sequential sums, separate multiply and add: build with -ffp-contract=off) and every quirk
