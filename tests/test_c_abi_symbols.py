@@ -19,8 +19,9 @@ def test_header_symbols_exported():
     import pareben_amd
     L = pareben_amd.load_library()
     names = _declared()
-    assert {"pareben_ctx_create", "pareben_ctx_run", "pareben_ctx_destroy", "pareben_cv_grid",
-            "pareben_fit_gaussian", "pareben_version", "pareben_last_error"} <= set(names)
+    assert {"pareben_ctx_create", "pareben_ctx_run", "pareben_ctx_destroy", "pareben_cv_grid", "pareben_cv_grid_multi",
+            "pareben_lambda_max_pairs", "pareben_fit_gaussian", "pareben_fit_gaussian_epis", "pareben_fit_binomial",
+            "pareben_fit_binomial_epis", "pareben_ctx_gram", "pareben_version", "pareben_last_error"} <= set(names)
     for n in names:
         assert hasattr(L, n), n
     assert b"gfx950" in L.pareben_version()
@@ -39,6 +40,12 @@ def test_no_cpu_fallback_and_loud_failure():
         pareben_amd.Context(X, y, fid, 2)                 # no device -> error, never a CPU path
     with pytest.raises(pareben_amd.ParebenError):
         pareben_amd.fit_gaussian(X, y, 0.1, 0.5)
+    with pytest.raises(pareben_amd.ParebenError):
+        pareben_amd.fit_binomial(X, (y > 0).astype(float), 0.1, 0.5, epis=True)
+    with pytest.raises(pareben_amd.ParebenError):
+        pareben_amd.cv_grid_multi(X, y, fid, 2, np.array([1.0]), np.array([0.1]), n_gpu=0)     # no device: error, not a host loop
+    with pytest.raises(pareben_amd.ParebenError):
+        pareben_amd._lib.lambda_max_pairs(X, y)
 
 
 def test_product_does_not_import_oracle():
