@@ -495,6 +495,34 @@ def test_config2_cells_vs_oracle_fixture():
         assert tot[j] == want[n], n
 
 
+def test_small_and_ragged_shapes(oracle):
+    """The smallest designs the entry points accept, against the oracle: one column; two columns with their pair
+    (Epis: 3 columns, fewer than a matrix-core tile); five training rows; more folds than a multiple of anything; a
+    fold whose held-out set is one row; K = 129 (one column past a 128-block of gram_kernel) with N = 17 (one sample
+    past a 16-sample slab)."""
+    rng = np.random.default_rng(21)
+    cases = []
+    X1 = np.asfortranarray(rng.standard_normal((12, 1))); cases.append((X1, 2.0 * X1[:, 0] + 0.1 * rng.standard_normal(12), 3, False))
+    X2 = np.asfortranarray(rng.standard_normal((15, 2))); cases.append((X2, X2[:, 0] * X2[:, 1] + 0.1 * rng.standard_normal(15), 3, True))
+    X3 = np.asfortranarray(rng.standard_normal((7, 4))); cases.append((X3, X3[:, 2] + 0.05 * rng.standard_normal(7), 7, False))     # leave-one-out
+    X4 = np.asfortranarray(rng.standard_normal((26, 129))); cases.append((X4, X4[:, 128] - X4[:, 0] + 0.1 * rng.standard_normal(26), 3, False))
+    for X, y, nf, epis in cases:
+        fid = AssignToFolds(X, nf)
+        alpha, lam = BuildGrid(X, y, nf, "yes" if epis else "no")
+        sel = np.arange(0, 400, 23)
+        with pareben_amd.Context(X, y, fid, nf, epis=epis) as ctx:
+            E, st, cnt = ctx.run(alpha[sel], lam[sel])
+        Eo, co, rc = oracle.cv_grid(X, y, fid, nf, alpha[sel], lam[sel], epis=epis)
+        ok = (st & 9) == 0
+        assert ok.mean() > 0.9
+        assert _rel(E[ok], Eo[ok]).max() < 1e-7, (X.shape, epis)
+    # argument errors of the epistasis entries
+    with pytest.raises(pareben_amd.ParebenError):
+        pareben_amd.fit_gaussian(X1, np.zeros(12), 0.1, 0.5, epis=True)          # one column has no pair
+    with pytest.raises(pareben_amd.ParebenError):
+        pareben_amd.fit_binomial(X1, np.zeros(12), 0.1, 0.5, epis=True)
+
+
 def test_lambda_max_pair_pass_on_device(golden, yeast):
     """pareben_lambda_max_pairs (R/BuildGrid.R:21-30 on the GPU) against the numpy restatement of the same R
     expressions: bundled BASIS (with an all-zero pair column: 0/0 never wins), a Gaussian design with ragged n, and the
