@@ -106,10 +106,63 @@ DEVNI void bm_weighted_rows(const Blk &B, const FoldDev &F, const BmWork &W, int
             W.BP[(size_t)i * ld + p] = a / F.scale[i];
         }
 #else
-    // A small GEMM, X' (diag(w) Phi).  The weighted model columns Z_p = w .* Phi_p are staged in LDS (as many
-    // columns as fit, sample-contiguous), so the per-column work of a feature is "coalesced design column
-    // (L1-resident after the first column) x LDS column + one wave reduction", with no dependent
-    // used[] -> rscale[] -> column address chain per column.
+    // A small GEMM, X' (diag(w) Phi), on the FP64 matrix cores when the weighted model columns fit in LDS 16 at a
+    // time: Z_p = w .* Phi_p staged sample-contiguous with an odd pitch (zero-padded to whole 4-sample groups and
+    // whole 16-column tiles); a wave owns 16 features and all column tiles, walks the samples four at a time --
+    // A operand: lane l holds x[feature l & 15][sample h0 + (l >> 4)] straight from memory (the four lanes of a
+    // feature read consecutive samples; the line stays in L1 for the next three steps), B operand from LDS -- and
+    // each accumulator tile is one fma chain over the samples in ascending order.  D register r of lane l is
+    // BP[feature (l >> 4) + 4 r][column l & 15]: rows of BP leave as 128-byte segments.
+    {
+        typedef double bd4 __attribute__((ext_vector_type(4)));
+        constexpr int MAXCT = 8;
+        const int Nr = (N + 3) & ~3, pitch = Nr + 1;
+        int pcm = (B.pool_n / pitch) & ~15;
+        if (pcm > 16 * MAXCT) pcm = 16 * MAXCT;
+        if (pcm >= 16) {
+            double *Z = B.pool;                                // [column][pitch]
+            const int l15 = B.lane & 15, l4 = B.lane >> 4;
+            for (int p0 = 0; p0 < M; p0 += pcm) {
+                const int pn = M - p0 < pcm ? M - p0 : pcm, pn16 = (pn + 15) & ~15, nct = pn16 >> 4;
+                blk_sync(B);
+                for (int e = B.tid; e < pn16 * pitch; e += B.nthr) {
+                    const int pc = e / pitch, h = e - pc * pitch;
+                    Z[e] = (pc < pn && h < N) ? W.w[h] * BM_PHI(p0 + pc, h) : 0.0;
+                }
+                blk_sync(B);
+                for (int ft = B.wave; ft * 16 < K; ft += B.nwave) {
+                    const int il = ft * 16 + l15;
+                    const double *xa = F.X + (size_t)(il < K ? il : K - 1) * N;
+                    const double *zb = Z + (size_t)l15 * pitch + l4;
+                    bd4 acc[MAXCT];
+#pragma unroll
+                    for (int ct = 0; ct < MAXCT; ct++) acc[ct] = bd4{0, 0, 0, 0};
+                    double a_n = l4 < N ? xa[l4] : 0.0;
+                    for (int h0 = 0; h0 < Nr; h0 += 4) {
+                        const double a = a_n;
+                        const int hn = h0 + 4 + l4;
+                        a_n = hn < N ? xa[hn] : 0.0;           // next group's operand in flight behind this group's matrix ops
+#pragma unroll
+                        for (int ct = 0; ct < MAXCT; ct++)
+                            if (ct < nct) acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, zb[(size_t)ct * 16 * pitch + h0], acc[ct], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int ct = 0; ct < MAXCT; ct++) {
+                        if (ct >= nct) continue;
+                        const int col = ct * 16 + l15;
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int i = ft * 16 + l4 + 4 * r;
+                            if (i < K && col < pn) W.BP[(size_t)i * ld + p0 + col] = acc[ct][r] / F.scale[i];
+                        }
+                    }
+                }
+            }
+            blk_sync(B);
+            return;
+        }
+    }
+    // samples too many for a 16-column tile in LDS: vector-ALU version, as many columns as fit at a time
     int pcn = B.pool_n / N;
     if (pcn > M) pcn = M;
     if (pcn >= 1) {

@@ -15,7 +15,7 @@ os.environ["PAREBEN_PHASE_DUMP"] = path
 with pareben_amd.Context(X, y, fid, 5, prior="binomial") as ctx:
     E, st, cnt = ctx.run(alpha, lam)
     print("timing", ctx.last_timing(), ctx.launch_info())
-ph = np.fromfile(path, dtype=np.int64).reshape(-1, 8).astype(np.float64)
+ph = np.fromfile(path, dtype=np.int64).reshape(-1, 24).astype(np.float64)     # PH_N ticks per fit
 tot = ph[:, 7].sum()
 names = {0: "weighted rows (BP)", 1: "full-stat rest (bb, quad, out)", 2: "delta ML", 3: "actions", 5: "posterior mode (Newton)"}
 print("sum of per-fit ticks %.1f s over %d fits; longest fit %.3f s" % (tot / 1e8, len(ph), ph[:, 7].max() / 1e8))
