@@ -95,9 +95,13 @@ DEVNI double bm_data_error(const Blk &B, const FoldDev &F, const BmWork &W)
 
 // BP[i][p] = sum_h x_i[h] w[h] Phi_p[h] / |x_i| for all features i and model columns p < M;
 // also bb-style single columns through `only` (>= 0: only that column, written to W.bb).
-DEVNI void bm_weighted_rows(const Blk &B, const FoldDev &F, const BmWork &W, int K, int M)
+// want_stats (device build): also bb_i = x_i' diag(w) x_i -> W.bb[i] and ze_i = x_i' e -> W.aroot[i] (what the
+// full-stat pass needs per feature, NEmainEff.c:1745-1757), taken from the same pass over the design columns.
+// Returns 1 when it did (matrix-core path), 0 when the caller has to compute them.
+DEVNI int bm_weighted_rows(const Blk &B, const FoldDev &F, const BmWork &W, int K, int M, bool want_stats = false)
 {
     const int N = F.N, ld = W.ld;
+    (void)want_stats;
 #ifdef PAREBEN_HOST_EMUL
     for (int i = 0; i < K; i++)
         for (int p = 0; p < M; p++) {
@@ -137,14 +141,26 @@ DEVNI void bm_weighted_rows(const Blk &B, const FoldDev &F, const BmWork &W, int
                     bd4 acc[MAXCT];
 #pragma unroll
                     for (int ct = 0; ct < MAXCT; ct++) acc[ct] = bd4{0, 0, 0, 0};
+                    const bool stats = want_stats && p0 == 0;
+                    double bbq = 0, ze = 0;
                     double a_n = l4 < N ? xa[l4] : 0.0;
                     for (int h0 = 0; h0 < Nr; h0 += 4) {
                         const double a = a_n;
                         const int hn = h0 + 4 + l4;
                         a_n = hn < N ? xa[hn] : 0.0;           // next group's operand in flight behind this group's matrix ops
+                        if (stats) {                           // a = 0 beyond the last sample
+                            const int hc = h0 + l4 < N ? h0 + l4 : N - 1;
+                            bbq += W.w[hc] * (a * a);
+                            ze += a * W.e[hc];
+                        }
 #pragma unroll
                         for (int ct = 0; ct < MAXCT; ct++)
                             if (ct < nct) acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, zb[(size_t)ct * 16 * pitch + h0], acc[ct], 0, 0, 0);
+                    }
+                    if (stats) {                               // the four sample groups of a feature sit 16 lanes apart
+                        bbq += __shfl_xor(bbq, 16, 64); bbq += __shfl_xor(bbq, 32, 64);
+                        ze += __shfl_xor(ze, 16, 64); ze += __shfl_xor(ze, 32, 64);
+                        if (l4 == 0 && il < K) { W.bb[il] = bbq; W.aroot[il] = ze; }
                     }
 #pragma unroll
                     for (int ct = 0; ct < MAXCT; ct++) {
@@ -159,7 +175,7 @@ DEVNI void bm_weighted_rows(const Blk &B, const FoldDev &F, const BmWork &W, int
                 }
             }
             blk_sync(B);
-            return;
+            return 1;
         }
     }
     // samples too many for a 16-column tile in LDS: vector-ALU version, as many columns as fit at a time
@@ -223,7 +239,67 @@ DEVNI void bm_weighted_rows(const Blk &B, const FoldDev &F, const BmWork &W, int
     }
 #endif
     blk_sync(B);
+    return 0;
 }
+
+#ifndef PAREBEN_HOST_EMUL
+// S_in = bb_i / |x_i|^2 - BP_i' Sigma BP_i and Q_in = ze_i / |x_i| for every feature (NEmainEff.c:1732-1762), the
+// quadratic forms on the FP64 matrix cores: a wave owns 16 features; T = BP_tile * Sigma in 16 x 16 tiles (A operand:
+// lane l holds BP[feature l & 15][k0 + (l >> 4)], B operand Sigma[k0 + (l >> 4)][16 ct + (l & 15)], 64 columns of Sigma
+// per round), folded with BP on the fly: D register r of lane l is T[feature (l >> 4) + 4 r][column l & 15], multiplied
+// by the same BP entry and summed over the 16 lanes of a row group.
+DEVNI void bm_quad_features(const Blk &B, const FoldDev &F, const BmWork &W, int K, int M)
+{
+    typedef double bd4 __attribute__((ext_vector_type(4)));
+    const int ld = W.ld, l15 = B.lane & 15, l4 = B.lane >> 4;
+    const int nct = (M + 15) >> 4;
+    for (int ft = B.wave; ft * 16 < K; ft += B.nwave) {
+        const int ia = ft * 16 + l15;
+        const double *bpa = W.BP + (size_t)(ia < K ? ia : K - 1) * ld;
+        double q[4] = {0, 0, 0, 0};
+        for (int c0 = 0; c0 < nct; c0 += 4) {
+            bd4 acc[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[c] = bd4{0, 0, 0, 0};
+            for (int k0 = 0; k0 < M; k0 += 4) {
+                const int k = k0 + l4;
+                const double a = (k < M && ia < K) ? bpa[k] : 0.0;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const int col = (c0 + c) * 16 + l15;
+                    if (c0 + c < nct) {
+                        const double b = (k < M && col < M) ? W.Sig[(size_t)k * ld + col] : 0.0;
+                        acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[c], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int col = (c0 + c) * 16 + l15;
+                if (c0 + c < nct && col < M) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int i = ft * 16 + l4 + 4 * r;
+                        if (i < K) q[r] += acc[c][r] * W.BP[(size_t)i * ld + col];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            double v = q[r];
+            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+            const int i = ft * 16 + l4 + 4 * r;
+            if (l15 == 0 && i < K) {
+                const double sc = F.scale[i];
+                W.Sin[i] = W.bb[i] / (sc * sc) - v;
+                W.Qin[i] = W.aroot[i] / sc;
+            }
+        }
+    }
+    blk_sync(B);
+}
+#endif
 
 // posterior mode, :1808-2010.  Leaves w, Sig (= H^-1), H from its last Hessian evaluation.
 DEVNI int bm_postmode(const Blk &B, const FoldDev &F, const BmWork &W, GmScalars &S)
@@ -346,7 +422,7 @@ DEVNI int bm_fullstat(const Blk &B, const FoldDev &F, const BmWork &W, int K, Gm
     bm_phi_mu(B, F, W, M, W.mu, W.pm);
     PAR(h, N) { const double y = 1 / (1 + exp(-W.pm[h])); W.e[h] = F.y[h] - y; }
     blk_sync(B);
-    bm_weighted_rows(B, F, W, K, M);
+    const int have_stats = bm_weighted_rows(B, F, W, K, M, true);
     S.bp_ok = M;
     PH_END(PH_FS_FEAT);
     // S_in = x_i' diag(w) x_i / |x_i|^2 - BP_i' Sigma BP_i ;  Q_in = x_i' e / |x_i|
@@ -361,15 +437,19 @@ DEVNI int bm_fullstat(const Blk &B, const FoldDev &F, const BmWork &W, int K, Gm
         W.bb[i] = bbq; W.aroot[i] = ze;        // scratch: aroot is rewritten by every dML pass
     }
 #else
-    for (int i = B.wave; i < K; i += B.nwave) {
-        const double *x = F.X + (size_t)i * N;
-        double bbq = 0, ze = 0;
-        for (int h = B.lane; h < N; h += 64) { const double xv = x[h]; bbq += W.w[h] * (xv * xv); ze += xv * W.e[h]; }
-        bbq = wave_sum(bbq); ze = wave_sum(ze);
-        if (B.lane == 0) { W.bb[i] = bbq; W.aroot[i] = ze; }
+    if (!have_stats) {
+        for (int i = B.wave; i < K; i += B.nwave) {
+            const double *x = F.X + (size_t)i * N;
+            double bbq = 0, ze = 0;
+            for (int h = B.lane; h < N; h += 64) { const double xv = x[h]; bbq += W.w[h] * (xv * xv); ze += xv * W.e[h]; }
+            bbq = wave_sum(bbq); ze = wave_sum(ze);
+            if (B.lane == 0) { W.bb[i] = bbq; W.aroot[i] = ze; }
+        }
     }
 #endif
     blk_sync(B);
+#ifdef PAREBEN_HOST_EMUL
+    (void)have_stats;
     PAR(i, K) {
         const double *bp = W.BP + (size_t)i * ld;
         double quad = 0;
@@ -383,6 +463,9 @@ DEVNI int bm_fullstat(const Blk &B, const FoldDev &F, const BmWork &W, int K, Gm
         W.Qin[i] = W.aroot[i] / sc;
     }
     blk_sync(B);
+#else
+    bm_quad_features(B, F, W, K, M);
+#endif
     PAR(i, K) {
         const double s = W.Sin[i], q = W.Qin[i];
         const int l = W.upos[i];
