@@ -69,6 +69,30 @@ DEV GmWork bm_as_gm(const BmWork &W)
 DEVNI void bm_phi_mu(const Blk &B, const FoldDev &F, const BmWork &W, int M, const double *mu, double *out)
 {
     const int N = F.N;
+#ifndef PAREBEN_HOST_EMUL
+    if (3 * M + 8 <= B.pool_n) {
+        // column ids, norms and coefficients staged in LDS first: the loop then has one coalesced design-column load per
+        // term and nothing behind a used[] -> rscale[] address chain; same expression, same order
+        double *lm = B.pool, *ls = B.pool + M;
+        int *lu = (int *)(B.pool + 2 * M);
+        blk_sync(B);
+        PAR(p, M) { lm[p] = mu[p]; if (p >= 1) { const int u = W.used[p - 1]; lu[p] = u; ls[p] = W.phi_div ? F.scale[u] : F.rscale[u]; } }
+        blk_sync(B);
+        const bool dv = W.phi_div != 0;
+        PAR(h, N) {
+            double a = 0;
+            a += 1.0 * lm[0];
+#pragma unroll 4
+            for (int p = 1; p < M; p++) {
+                const double x = F.X[(size_t)lu[p] * N + h];
+                a += (dv ? x / ls[p] : x * ls[p]) * lm[p];
+            }
+            out[h] = a;
+        }
+        blk_sync(B);
+        return;
+    }
+#endif
     PAR(h, N) {
         double a = 0;
         for (int p = 0; p < M; p++) a += BM_PHI(p, h) * mu[p];
@@ -351,7 +375,43 @@ DEVNI int bm_postmode(const Blk &B, const FoldDev &F, const BmWork &W, GmScalars
             ga = wave_sum(ga); ha = wave_sum(ha);
             if (B.lane == 0) { W.g[j] = ga - W.A[j - 1] * W.mu[j]; W.H[j] = ha; W.H[(size_t)j * ld] = ha; }
         }
-        {   // lower triangle of Phi' diag(w) Phi, one wavefront per (j, k) pair
+        if (M - 1 >= 8) {
+            // Phi' diag(w) Phi on the FP64 matrix cores: 16 x 16 tiles over the model columns 1 .. M-1, lower-triangle tile
+            // pairs dealt to the waves; A operand (phi_j w) and B operand phi_k straight from the design (lane l: column
+            // l & 15 of the tile, sample h0 + (l >> 4)), one fma chain over the samples in ascending order -- the product is
+            // associated as the reference does, (phi_j * w) * phi_k (:1911)
+            typedef double bd4 __attribute__((ext_vector_type(4)));
+            const int Mm = M - 1, nT = (Mm + 15) >> 4, l15 = B.lane & 15, l4 = B.lane >> 4;
+            const int Nr = (N + 3) & ~3;
+            for (int q = B.wave; q < nT * (nT + 1) / 2; q += B.nwave) {
+                int tj = (int)((sqrt(8.0 * q + 1.0) - 1.0) * 0.5);
+                while ((tj + 1) * (tj + 2) / 2 <= q) tj++;
+                while (tj * (tj + 1) / 2 > q) tj--;
+                const int tk = q - tj * (tj + 1) / 2;              // tk <= tj
+                const int ja = tj * 16 + l15, kb = tk * 16 + l15;  // model columns (0-based among 1 .. M-1) of this lane's operands
+                const int uj = W.used[ja < Mm ? ja : Mm - 1], uk = W.used[kb < Mm ? kb : Mm - 1];
+                const double *xj = F.X + (size_t)uj * N, *xk = F.X + (size_t)uk * N;
+                const double sj = W.phi_div ? F.scale[uj] : F.rscale[uj], sk = W.phi_div ? F.scale[uk] : F.rscale[uk];
+                const bool dv = W.phi_div != 0;
+                bd4 acc = bd4{0, 0, 0, 0};
+                for (int h0 = 0; h0 < Nr; h0 += 4) {
+                    const int h = h0 + l4, hc = h < N ? h : N - 1;
+                    const double pj = dv ? xj[hc] / sj : xj[hc] * sj, pk = dv ? xk[hc] / sk : xk[hc] * sk;
+                    const double a = (h < N && ja < Mm) ? pj * W.w[hc] : 0.0;
+                    const double b = (h < N && kb < Mm) ? pk : 0.0;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int jm = tj * 16 + l4 + 4 * r, km = tk * 16 + l15;
+                    if (jm < Mm && km < Mm && km <= jm) {
+                        double v = acc[r];
+                        if (jm == km) v += W.A[km];
+                        W.H[(size_t)(km + 1) * ld + jm + 1] = v; W.H[(size_t)(jm + 1) * ld + km + 1] = v;
+                    }
+                }
+            }
+        } else {   // lower triangle of Phi' diag(w) Phi, one wavefront per (j, k) pair
             const int np = (M - 1) * M / 2;
             for (int q = B.wave; q < np; q += B.nwave) {
                 int j = (int)((sqrt(8.0 * q + 1.0) - 1.0) * 0.5);
