@@ -167,19 +167,37 @@ DEVNI int bm_weighted_rows(const Blk &B, const FoldDev &F, const BmWork &W, int 
                     for (int ct = 0; ct < MAXCT; ct++) acc[ct] = bd4{0, 0, 0, 0};
                     const bool stats = want_stats && p0 == 0;
                     double bbq = 0, ze = 0;
-                    double a_n = l4 < N ? xa[l4] : 0.0;
-                    for (int h0 = 0; h0 < Nr; h0 += 4) {
-                        const double a = a_n;
-                        const int hn = h0 + 4 + l4;
-                        a_n = hn < N ? xa[hn] : 0.0;           // next group's operand in flight behind this group's matrix ops
-                        if (stats) {                           // a = 0 beyond the last sample
-                            const int hc = h0 + l4 < N ? h0 + l4 : N - 1;
-                            bbq += W.w[hc] * (a * a);
-                            ze += a * W.e[hc];
+                    // eight 4-sample steps per round: the round's eight operand loads (+ weights / residuals) are issued
+                    // together, one round ahead of the matrix ops that consume them (a load per step, consumed at once,
+                    // made every step wait a memory round trip: 4x slower)
+                    constexpr int RS = 8;
+                    double an[RS], wn[RS], en[RS];
+#pragma unroll
+                    for (int u = 0; u < RS; u++) {
+                        const int h = 4 * u + l4, hc = h < N ? h : N - 1;
+                        an[u] = h < N ? xa[hc] : 0.0;
+                        wn[u] = stats ? W.w[hc] : 0.0; en[u] = stats ? W.e[hc] : 0.0;
+                    }
+                    for (int h0 = 0; h0 < Nr; h0 += 4 * RS) {
+                        double ac[RS], wc[RS], ec[RS];
+#pragma unroll
+                        for (int u = 0; u < RS; u++) { ac[u] = an[u]; wc[u] = wn[u]; ec[u] = en[u]; }
+#pragma unroll
+                        for (int u = 0; u < RS; u++) {
+                            const int h = h0 + 4 * RS + 4 * u + l4, hc = h < N ? h : N - 1;
+                            an[u] = h < N ? xa[hc] : 0.0;
+                            if (stats) { wn[u] = W.w[hc]; en[u] = W.e[hc]; }
                         }
 #pragma unroll
-                        for (int ct = 0; ct < MAXCT; ct++)
-                            if (ct < nct) acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, zb[(size_t)ct * 16 * pitch + h0], acc[ct], 0, 0, 0);
+                        for (int u = 0; u < RS; u++) {
+                            if (h0 + 4 * u < Nr) {
+                                const double a = ac[u];
+                                if (stats) { bbq += wc[u] * (a * a); ze += a * ec[u]; }      // a = 0 beyond the last sample
+#pragma unroll
+                                for (int ct = 0; ct < MAXCT; ct++)
+                                    if (ct < nct) acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, zb[(size_t)ct * 16 * pitch + h0 + 4 * u], acc[ct], 0, 0, 0);
+                            }
+                        }
                     }
                     if (stats) {                               // the four sample groups of a feature sit 16 lanes apart
                         bbq += __shfl_xor(bbq, 16, 64); bbq += __shfl_xor(bbq, 32, 64);
@@ -394,12 +412,26 @@ DEVNI int bm_postmode(const Blk &B, const FoldDev &F, const BmWork &W, GmScalars
                 const double sj = W.phi_div ? F.scale[uj] : F.rscale[uj], sk = W.phi_div ? F.scale[uk] : F.rscale[uk];
                 const bool dv = W.phi_div != 0;
                 bd4 acc = bd4{0, 0, 0, 0};
-                for (int h0 = 0; h0 < Nr; h0 += 4) {
-                    const int h = h0 + l4, hc = h < N ? h : N - 1;
-                    const double pj = dv ? xj[hc] / sj : xj[hc] * sj, pk = dv ? xk[hc] / sk : xk[hc] * sk;
-                    const double a = (h < N && ja < Mm) ? pj * W.w[hc] : 0.0;
-                    const double b = (h < N && kb < Mm) ? pk : 0.0;
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+                constexpr int RS = 8;                              // eight steps' operand loads issued together, one round ahead
+                double xjn[RS], xkn[RS], wn[RS];
+#pragma unroll
+                for (int u = 0; u < RS; u++) { const int h = 4 * u + l4, hc = h < N ? h : N - 1; xjn[u] = xj[hc]; xkn[u] = xk[hc]; wn[u] = W.w[hc]; }
+                for (int h0 = 0; h0 < Nr; h0 += 4 * RS) {
+                    double xjc[RS], xkc[RS], wc[RS];
+#pragma unroll
+                    for (int u = 0; u < RS; u++) { xjc[u] = xjn[u]; xkc[u] = xkn[u]; wc[u] = wn[u]; }
+#pragma unroll
+                    for (int u = 0; u < RS; u++) { const int h = h0 + 4 * RS + 4 * u + l4, hc = h < N ? h : N - 1; xjn[u] = xj[hc]; xkn[u] = xk[hc]; wn[u] = W.w[hc]; }
+#pragma unroll
+                    for (int u = 0; u < RS; u++) {
+                        const int h = h0 + 4 * u + l4;
+                        if (h0 + 4 * u < Nr) {
+                            const double pj = dv ? xjc[u] / sj : xjc[u] * sj, pk = dv ? xkc[u] / sk : xkc[u] * sk;
+                            const double a = (h < N && ja < Mm) ? pj * wc[u] : 0.0;
+                            const double b = (h < N && kb < Mm) ? pk : 0.0;
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+                        }
+                    }
                 }
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
