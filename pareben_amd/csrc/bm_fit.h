@@ -119,11 +119,61 @@ DEVNI double bm_data_error(const Blk &B, const FoldDev &F, const BmWork &W)
 
 // BP[i][p] = sum_h x_i[h] w[h] Phi_p[h] / |x_i| for all features i and model columns p < M;
 // also bb-style single columns through `only` (>= 0: only that column, written to W.bb).
+#ifndef PAREBEN_HOST_EMUL
+// One 16-feature tile of bm_weighted_rows on the matrix cores, NCT column tiles of the staged block (compile-time: no
+// guards around the matrix ops), EXT = the staged block carries the residual column (statistics wanted).
+template <int NCT, int EXT>
+DEV void bm_wr_tile(gptr_cd xa, lptr_d zb, lptr_d lw, int pitch, int Nu, int Nr, int l4, double (&out)[NCT][4], double &bbq_out)
+{
+    typedef double bd4 __attribute__((ext_vector_type(4)));
+    constexpr int RS = 8;
+    bd4 acc[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ct++) acc[ct] = bd4{0, 0, 0, 0};
+    double bbq = 0;
+    double an[RS];
+#pragma unroll
+    for (int u = 0; u < RS; u++) { const int h = 4 * u + l4; an[u] = xa[h < Nu ? h : Nu - 1]; }
+    double bn[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ct++) bn[ct] = zb[ct * 16 * pitch];
+    for (int h0 = 0; h0 < Nr; h0 += 4 * RS) {
+        double ac[RS];
+#pragma unroll
+        for (int u = 0; u < RS; u++) ac[u] = (h0 + 4 * u + l4 < Nu) ? an[u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < RS; u++) { const int h = h0 + 4 * RS + 4 * u + l4; an[u] = xa[h < Nu ? h : Nu - 1]; }
+#pragma unroll
+        for (int u = 0; u < RS; u++) {
+            const int hs = h0 + 4 * u;                             // wave-uniform
+            if (hs < Nr) {
+                double bc[NCT];
+#pragma unroll
+                for (int ct = 0; ct < NCT; ct++) bc[ct] = bn[ct];
+                const int hn = hs + 4 < Nr ? hs + 4 : hs;           // next step's B operands behind this step's matrix ops
+#pragma unroll
+                for (int ct = 0; ct < NCT; ct++) bn[ct] = zb[ct * 16 * pitch + hn];
+                const double a = ac[u];
+#pragma unroll
+                for (int ct = 0; ct < NCT; ct++) acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bc[ct], acc[ct], 0, 0, 0);
+                if (EXT) bbq += lw[hs + l4] * (a * a);
+            }
+        }
+    }
+#pragma unroll
+    for (int ct = 0; ct < NCT; ct++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) out[ct][r] = acc[ct][r];
+    bbq_out = bbq;
+}
+#endif
+
 // want_stats (device build): also bb_i = x_i' diag(w) x_i -> W.bb[i] and ze_i = x_i' e -> W.aroot[i] (what the
 // full-stat pass needs per feature, NEmainEff.c:1745-1757), taken from the same pass over the design columns.
 // Returns 1 when it did (matrix-core path), 0 when the caller has to compute them.
-DEVNI int bm_weighted_rows(const Blk &B, const FoldDev &F, const BmWork &W, int K, int M, bool want_stats = false)
+DEVNI int bm_weighted_rows(const Blk &B, const FoldDev &F, const BmWork &W, int K, int M, bool want_stats = false, long long *phx = nullptr)
 {
+    (void)phx;
     const int N = F.N, ld = W.ld;
     (void)want_stats;
 #ifdef PAREBEN_HOST_EMUL
@@ -138,72 +188,64 @@ DEVNI int bm_weighted_rows(const Blk &B, const FoldDev &F, const BmWork &W, int 
     // time: Z_p = w .* Phi_p staged sample-contiguous with an odd pitch (zero-padded to whole 4-sample groups and
     // whole 16-column tiles); a wave owns 16 features and all column tiles, walks the samples four at a time --
     // A operand: lane l holds x[feature l & 15][sample h0 + (l >> 4)] straight from memory (the four lanes of a
-    // feature read consecutive samples; the line stays in L1 for the next three steps), B operand from LDS -- and
-    // each accumulator tile is one fma chain over the samples in ascending order.  D register r of lane l is
+    // feature read consecutive samples; the line stays in L1 for the next three steps; eight steps' loads are issued
+    // together, a round ahead of the matrix ops that use them), B operand from LDS one step ahead -- and each
+    // accumulator tile is one fma chain over the samples in ascending order.  D register r of lane l is
     // BP[feature (l >> 4) + 4 r][column l & 15]: rows of BP leave as 128-byte segments.
+    // want_stats: one more staged column, e: x_i'e falls out of the same products (column pn); x_i' diag(w) x_i is summed
+    // on the vector ALU from the operand already in registers and the weights staged behind the columns.
+    // Everything the loop branches on is put in SGPRs (arguments of a non-inlined function arrive in VGPRs: a guard on
+    // them becomes an exec mask around every matrix op) and LDS / global pointers carry their address space (a generic
+    // pointer makes every operand read a flat load followed by s_waitcnt vmcnt(0), which drains the prefetch).
     {
         typedef double bd4 __attribute__((ext_vector_type(4)));
-        constexpr int MAXCT = 8;
-        const int Nr = (N + 3) & ~3, pitch = Nr + 1;
-        int pcm = (B.pool_n / pitch) & ~15;
+        constexpr int MAXCT = 4;
+        const int Nu = uni(N), Ku = uni(K), Mu = uni(M), ldu = uni(ld), ws = uni(want_stats ? 1 : 0);
+        const int Nr = (Nu + 3) & ~3, pitch = Nr + 1;
+        int pcm = ((uni(B.pool_n) - (ws ? Nr : 0)) / pitch) & ~15;
         if (pcm > 16 * MAXCT) pcm = 16 * MAXCT;
         if (pcm >= 16) {
-            double *Z = B.pool;                                // [column][pitch]
-            const int l15 = B.lane & 15, l4 = B.lane >> 4;
-            for (int p0 = 0; p0 < M; p0 += pcm) {
-                const int pn = M - p0 < pcm ? M - p0 : pcm, pn16 = (pn + 15) & ~15, nct = pn16 >> 4;
+            const lptr_d Z = as_lds(uni_ptr(B.pool));          // [column][pitch]
+            const gptr_cd gX = as_global(uni_ptr(F.X)), gw = as_global(uni_ptr(W.w)), ge = as_global(uni_ptr(W.e));
+            const gptr_cd gsc = as_global(uni_ptr(F.scale));
+            const gptr_d gBP = as_global_rw(uni_ptr(W.BP)), gbb = as_global_rw(uni_ptr(W.bb)), gze = as_global_rw(uni_ptr(W.aroot));
+            const int lane = B.lane, wave = uni(B.wave), nwave = uni(B.nwave), tid = B.tid, nthr = uni(B.nthr);
+            const int l15 = lane & 15, l4 = lane >> 4;
+            for (int p0 = 0; p0 < Mu; p0 += 0) {
+                const int ext = (ws && p0 == 0) ? 1 : 0;
+                const int pn = Mu - p0 < pcm - ext ? Mu - p0 : pcm - ext;
+                const int pn16 = (pn + ext + 15) & ~15, nct = pn16 >> 4;
+                const lptr_d lw = Z + pcm * pitch;                     // the weights, zero beyond the last sample
                 blk_sync(B);
-                for (int e = B.tid; e < pn16 * pitch; e += B.nthr) {
+                PHX_BEGIN(t_st);
+                for (int e = tid; e < pn16 * pitch; e += nthr) {
                     const int pc = e / pitch, h = e - pc * pitch;
-                    Z[e] = (pc < pn && h < N) ? W.w[h] * BM_PHI(p0 + pc, h) : 0.0;
+                    double v = 0.0;
+                    if (h < Nu) {
+                        if (pc < pn) v = gw[h] * BM_PHI(p0 + pc, h);
+                        else if (ext && pc == pn) v = ge[h];
+                    }
+                    Z[e] = v;
                 }
+                if (ext) for (int h = tid; h < Nr; h += nthr) lw[h] = h < Nu ? gw[h] : 0.0;
                 blk_sync(B);
-                for (int ft = B.wave; ft * 16 < K; ft += B.nwave) {
+                PHX_END(t_st, PH_HBUILD);
+                PHX_BEGIN(t_mm);
+                for (int ft = wave; ft * 16 < Ku; ft += nwave) {
                     const int il = ft * 16 + l15;
-                    const double *xa = F.X + (size_t)(il < K ? il : K - 1) * N;
-                    const double *zb = Z + (size_t)l15 * pitch + l4;
-                    bd4 acc[MAXCT];
-#pragma unroll
-                    for (int ct = 0; ct < MAXCT; ct++) acc[ct] = bd4{0, 0, 0, 0};
-                    const bool stats = want_stats && p0 == 0;
-                    double bbq = 0, ze = 0;
-                    // eight 4-sample steps per round: the round's eight operand loads (+ weights / residuals) are issued
-                    // together, one round ahead of the matrix ops that consume them (a load per step, consumed at once,
-                    // made every step wait a memory round trip: 4x slower)
-                    constexpr int RS = 8;
-                    double an[RS], wn[RS], en[RS];
-#pragma unroll
-                    for (int u = 0; u < RS; u++) {
-                        const int h = 4 * u + l4, hc = h < N ? h : N - 1;
-                        an[u] = h < N ? xa[hc] : 0.0;
-                        wn[u] = stats ? W.w[hc] : 0.0; en[u] = stats ? W.e[hc] : 0.0;
-                    }
-                    for (int h0 = 0; h0 < Nr; h0 += 4 * RS) {
-                        double ac[RS], wc[RS], ec[RS];
-#pragma unroll
-                        for (int u = 0; u < RS; u++) { ac[u] = an[u]; wc[u] = wn[u]; ec[u] = en[u]; }
-#pragma unroll
-                        for (int u = 0; u < RS; u++) {
-                            const int h = h0 + 4 * RS + 4 * u + l4, hc = h < N ? h : N - 1;
-                            an[u] = h < N ? xa[hc] : 0.0;
-                            if (stats) { wn[u] = W.w[hc]; en[u] = W.e[hc]; }
-                        }
-#pragma unroll
-                        for (int u = 0; u < RS; u++) {
-                            if (h0 + 4 * u < Nr) {
-                                const double a = ac[u];
-                                if (stats) { bbq += wc[u] * (a * a); ze += a * ec[u]; }      // a = 0 beyond the last sample
-#pragma unroll
-                                for (int ct = 0; ct < MAXCT; ct++)
-                                    if (ct < nct) acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, zb[(size_t)ct * 16 * pitch + h0 + 4 * u], acc[ct], 0, 0, 0);
-                            }
-                        }
-                    }
-                    if (stats) {                               // the four sample groups of a feature sit 16 lanes apart
-                        bbq += __shfl_xor(bbq, 16, 64); bbq += __shfl_xor(bbq, 32, 64);
-                        ze += __shfl_xor(ze, 16, 64); ze += __shfl_xor(ze, 32, 64);
-                        if (l4 == 0 && il < K) { W.bb[il] = bbq; W.aroot[il] = ze; }
-                    }
+                    const gptr_cd xa = gX + (size_t)(il < Ku ? il : Ku - 1) * Nu;
+                    const lptr_d zb = Z + l15 * pitch + l4;
+                    double acc[MAXCT][4];
+                    double bbq = 0;
+#define BM_WR_CASE(n)                                                                                                   \
+                    case n: {                                                                                           \
+                        double o[n][4];                                                                                 \
+                        if (ext) bm_wr_tile<n, 1>(xa, zb, lw, pitch, Nu, Nr, l4, o, bbq);                               \
+                        else bm_wr_tile<n, 0>(xa, zb, lw, pitch, Nu, Nr, l4, o, bbq);                                   \
+                        _Pragma("unroll") for (int ct = 0; ct < n; ct++) _Pragma("unroll") for (int r = 0; r < 4; r++) acc[ct][r] = o[ct][r]; \
+                    } break;
+                    switch (nct) { BM_WR_CASE(1) BM_WR_CASE(2) BM_WR_CASE(3) default: BM_WR_CASE(4) }
+#undef BM_WR_CASE
 #pragma unroll
                     for (int ct = 0; ct < MAXCT; ct++) {
                         if (ct >= nct) continue;
@@ -211,10 +253,19 @@ DEVNI int bm_weighted_rows(const Blk &B, const FoldDev &F, const BmWork &W, int 
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
                             const int i = ft * 16 + l4 + 4 * r;
-                            if (i < K && col < pn) W.BP[(size_t)i * ld + p0 + col] = acc[ct][r] / F.scale[i];
+                            if (i < Ku) {
+                                if (col < pn) gBP[(size_t)i * ldu + p0 + col] = acc[ct][r] / gsc[i];
+                                else if (ext && col == pn) gze[i] = acc[ct][r];
+                            }
                         }
                     }
+                    if (ext) {                                 // the four sample groups of a feature sit 16 lanes apart
+                        bbq += __shfl_xor(bbq, 16, 64); bbq += __shfl_xor(bbq, 32, 64);
+                        if (l4 == 0 && il < Ku) gbb[il] = bbq;
+                    }
                 }
+                PHX_END(t_mm, PH_MATVEC);
+                p0 += pn;
             }
             blk_sync(B);
             return 1;
@@ -514,7 +565,7 @@ DEVNI int bm_fullstat(const Blk &B, const FoldDev &F, const BmWork &W, int K, Gm
     bm_phi_mu(B, F, W, M, W.mu, W.pm);
     PAR(h, N) { const double y = 1 / (1 + exp(-W.pm[h])); W.e[h] = F.y[h] - y; }
     blk_sync(B);
-    const int have_stats = bm_weighted_rows(B, F, W, K, M, true);
+    const int have_stats = bm_weighted_rows(B, F, W, K, M, true, S.ph);
     S.bp_ok = M;
     PH_END(PH_FS_FEAT);
     // S_in = x_i' diag(w) x_i / |x_i|^2 - BP_i' Sigma BP_i ;  Q_in = x_i' e / |x_i|

@@ -22,5 +22,7 @@ print("sum of per-fit ticks %.1f s over %d fits; longest fit %.3f s" % (tot / 1e
 for k, n in names.items():
     print("  %-32s %6.2f %%" % (n, 100 * ph[:, k].sum() / tot))
 print("  %-32s %6.2f %%" % ("other", 100 * (tot - ph[:, list(names)].sum()) / tot))
+print("  inside the weighted-rows pass of the full-stat calls: staging w.*Phi in LDS %.2f %%, matrix-core loop %.2f %%" % (
+    100 * ph[:, 11].sum() / tot, 100 * ph[:, 8].sum() / tot))
 c = cnt.reshape(-1, cnt.shape[-1])
 print("per fit: inner %.1f adds %.1f dels %.1f reest %.1f fullstats %.1f" % tuple(c[:, k].mean() for k in (1, 2, 3, 4, 5)))
