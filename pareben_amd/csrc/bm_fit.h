@@ -20,9 +20,10 @@
 // The per-sample IRLS weights w = y(1-y) change at every mode update, so unlike the Gaussian
 // kernel nothing can be cached as a Gram matrix: every action needs the weighted cross products
 // BP[i][p] = x_i' diag(w) Phi_p / |x_i| of all K features with the M model columns.  They are
-// computed once per (mode update / action) by the whole workgroup -- one wavefront per feature,
-// lanes over samples (coalesced columns), xor-shuffle reductions -- into a K x M scratch matrix in
-// HBM and then reused by the M^2-per-feature quadratic forms.  Phi is never materialised: column 0
+// computed once per (mode update / action) by the whole workgroup into a K x M scratch matrix in
+// HBM -- a small GEMM on the FP64 matrix cores (bm_weighted_rows) -- and then reused by the
+// per-feature quadratic forms (bm_quad_features, matrix cores too); the Newton step's Hessian
+// Phi' diag(w) Phi is the third such product (bm_postmode).  Phi is never materialised: column 0
 // is the intercept, column l+1 is the design column of used[l] times 1/|x|.
 //
 // Reference quirks kept: Q1 first basis = column 0, force-deleted once;
