@@ -718,12 +718,20 @@ DEVNI void bm_add(const Blk &B, const FoldDev &F, const BmWork &W, int K, GmScal
     for (int i = 0; i < K; i++) { double a = 0; for (int h = 0; h < N; h++) a += F.X[(size_t)i * N + h] * W.bphi[h]; W.bb[i] = a / F.scale[i]; }
     for (int p = 0; p < M; p++) { double a = 0; for (int h = 0; h < N; h++) a += BM_PHI(p, h) * W.bphi[h]; W.tmp[p] = a; }
 #else
-    for (int i = B.wave; i < K; i += B.nwave) {
-        const double *x = F.X + (size_t)i * N;
-        double a = 0;
-        for (int h = B.lane; h < N; h += 64) a += x[h] * W.bphi[h];
-        a = wave_sum(a);
-        if (B.lane == 0) W.bb[i] = a / F.scale[i];
+    // eight features per wave and reduction tree: their loads are in flight together (a feature at a time paid a memory
+    // round trip per feature); wave_sum8 pairs lanes exactly like wave_sum, so the sums are the same bits
+    for (int i0 = B.wave * 8; i0 < K; i0 += B.nwave * 8) {
+        double a[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const double *x = F.X + (size_t)(i0 + c < K ? i0 + c : K - 1) * N;
+            double t = 0;
+            for (int h = B.lane; h < N; h += 64) t += x[h] * W.bphi[h];
+            a[c] = t;
+        }
+        wave_sum8(a, B.lane);
+        const int i = i0 + (B.lane >> 3);
+        if ((B.lane & 7) == 0 && i < K) W.bb[i] = a[0] / F.scale[i];
     }
     for (int p = B.wave; p < M; p += B.nwave) {
         double a = 0;
