@@ -1024,8 +1024,10 @@ static int run_enqueue(pareben_ctx *c, int n_cells, const double *alpha, const d
     // from the small-lambda end -- longest first, the short ones pack the tail (config 3: 8 % shorter than outside-in)
     const char *qenv = getenv("PAREBEN_QUEUE");                 // A/B: "outside-in" | "small-first"
     const bool small_first = qenv ? !strcmp(qenv, "small-first") : c->prior == PAREBEN_PRIOR_BINOMIAL;
+    const char *menv = getenv("PAREBEN_QUEUE_MIX");             // A/B: one cell from the small-lambda end per <n> (default 4)
+    const int qmix = (menv && atoi(menv) >= 2) ? atoi(menv) : 4;
     for (int k = 0, lo = 0, hi = n_cells - 1; k < n_cells; k++)
-        cells[k] = small_first ? sorted[n_cells - 1 - k] : (((k & 3) == 3) ? sorted[hi--] : sorted[lo++]);
+        cells[k] = small_first ? sorted[n_cells - 1 - k] : (((k % qmix) == qmix - 1) ? sorted[hi--] : sorted[lo++]);
     D.order.resize(n_units);
     for (int k = 0; k < n_cells; k++) for (int f = 0; f < nF; f++) D.order[k * nF + f] = cells[k] * nF + f;
 
