@@ -60,3 +60,16 @@ def yeast():
     n, p = int(d["n"]), int(d["p"])
     G = np.unpackbits(d["bits"], axis=0)[:n].astype(np.float64) * 2.0 - 1.0
     return np.asfortranarray(G), d["pheno"].astype(np.float64)
+
+
+@pytest.fixture(scope="session")
+def fulltest():
+    """Inputs and stored real-R outputs of paper_materials/Real Data Analysis/Full_Test (tools/make_golden_fulltest.py).
+    fulltest(name) -> (X, y, fixture); the rows the authors' runs saw (their read.delim() took the first sample as a
+    header line, Full_Test/dataprep.R:3-4), +-1 genotypes as doubles, column-major."""
+    def load(name):
+        d = np.load(os.path.join(GOLDEN, "fulltest_%s.npz" % name))
+        n, k = int(d["n"]), int(d["drop_first_row"])
+        X = np.unpackbits(d["bits"], axis=0)[:n].astype(np.float64)[k:] * 2.0 - 1.0
+        return np.asfortranarray(X), d["pheno"].astype(np.float64)[k:], d
+    return load

@@ -169,3 +169,33 @@ def test_oracle_reproduces_real_r_fit(golden, yeast):
     sse = float(np.sum((y[te] - pred) ** 2))
     assert abs(sse - want) <= 1e-12 * want, (sse, want)
     assert o["counters"]["m_final"] == len(nz) == 44 and o["counters"]["m_max"] == 393 and o["counters"]["n_inner"] == 490
+
+
+def test_oracle_reproduces_real_r_refits(fulltest):
+    """Second pin of oracle/eben_gm.c to the reference itself, at the level of a fit's full output: the three stored
+    EBelasticNet.Gaussian results paper_materials/Real Data Analysis/Full_Test/EBENoutput_epi0.08_residual*.RDS
+    (R 3.5 + CRAN EBEN, December 2018) recomputed on their inputs filter_matrix_epi0.08[, 2:202] + pheno_Zeo_residual
+    (3843 x 201 after the authors' header artefact, see the fixture) at (lambda, alpha) = (0.66258950402..., 0.05),
+    (0.6625895, 0.05), (0.6625895, 0.5): the same 109 features, effects / posterior variances, WaldScore, Intercept and
+    residVar of R's `weight` table and list (R/EBelasticNet.Gaussian.R:55-104 builds them from the C outputs)."""
+    import oracle_lib as O
+    X, y, d = fulltest("epi008")
+    assert X.shape == (3843, 201)
+    for tag in "abc":
+        R = d[tag + "_weight"]
+        o = O.fit_gaussian(X, y, float(d[tag + "_lambda"]), float(d[tag + "_alpha"]))
+        assert o["rc"] == 0 and o["counters"]["status"] == 0
+        nz = np.nonzero(o["Beta"][:, 2])[0]
+        assert np.array_equal(nz + 1, R[:, 0].astype(int)) and np.array_equal(R[:, 0], R[:, 1]) and len(nz) == 109
+        assert np.allclose(o["Beta"][nz, 2], R[:, 2], rtol=1e-9, atol=0)          # observed 3e-12 ... 2e-11
+        assert np.allclose(o["Beta"][nz, 3], R[:, 3], rtol=1e-11, atol=0)         # observed 2e-14
+        assert abs(o["wald"] - float(d[tag + "_WaldScore"])) <= 1e-12 * o["wald"]
+        assert abs(o["intercept"] - float(d[tag + "_Intercept"])) <= 1e-10 * abs(o["intercept"])
+        assert abs(o["residual"] - float(d[tag + "_residVar"])) <= 1e-13 * o["residual"]
+    # with the first sample kept (what the files hold, not what the runs saw) the fit is a different one: the artefact
+    # is part of the pinned inputs, not a tolerance
+    d0 = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "fulltest_epi008.npz"))
+    n = int(d0["n"])
+    Xall = np.asfortranarray(np.unpackbits(d0["bits"], axis=0)[:n].astype(np.float64) * 2 - 1)
+    o = O.fit_gaussian(Xall, d0["pheno"].astype(np.float64), float(d0["c_lambda"]), float(d0["c_alpha"]))
+    assert len(np.nonzero(o["Beta"][:, 2])[0]) != 109

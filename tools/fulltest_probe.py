@@ -1,0 +1,102 @@
+"""Real-R parity on the Full_Test fixtures (tools/make_golden_fulltest.py), on the GPU through the package:
+the six stored EBelasticNet.Gaussian fits and the stored 3-fold CrossValidate() table on the 19871-column design.
+Writes a JSON report (argv[1], default gpurun_out/fulltest_probe.json)."""
+import json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import pareben_amd
+from pareben_amd.grid import AssignToFolds, BuildGrid, summarise_cv
+
+G = os.path.join(ROOT, "tests", "golden")
+rep = {}
+
+
+def design(d):
+    n = int(d["n"]); k = int(d["drop_first_row"])
+    X = np.asfortranarray(np.unpackbits(d["bits"], axis=0)[:n].astype(np.float64)[k:] * 2 - 1)
+    return X, d["pheno"].astype(np.float64)[k:]
+
+
+def cmp_fit(out, d, pre=""):
+    W, R = out["weight"], d[pre + "weight"]
+    r = {"rows": int(W.shape[0]), "rows_r": int(R.shape[0])}
+    if W.shape == R.shape and np.array_equal(W[:, :2], R[:, :2]):
+        r["same_features"] = True
+        for j, nm in ((2, "beta"), (3, "var"), (4, "t"), (5, "p")):
+            r["max_rel_" + nm] = float(np.max(np.abs(W[:, j] - R[:, j]) / np.maximum(np.abs(R[:, j]), 1e-300)))
+    else:
+        r["same_features"] = False
+        r["common"] = int(len(set(W[:, 0].astype(int)) & set(R[:, 0].astype(int))))
+    for nm in ("WaldScore", "Intercept", "residVar"):
+        r["rel_" + nm] = float(abs(out[nm] - d[pre + nm]) / abs(d[pre + nm]))
+    return r
+
+
+t0 = time.time()
+d = np.load(G + "/fulltest_epi008.npz"); X, y = design(d)
+for tag in ("abc" if not os.environ.get("SKIP_SINGLE") else ""):
+    out = pareben_amd.EBelasticNet.Gaussian(X, y, float(d[tag + "_lambda"]), float(d[tag + "_alpha"]))
+    rep["epi008_" + tag] = cmp_fit(out, d, tag + "_")
+for name in (("zeo_main", "zeo_main_epi") if not os.environ.get("SKIP_SINGLE") else ()):
+    d = np.load(G + "/fulltest_%s.npz" % name); X, y = design(d)
+    t1 = time.time()
+    out = pareben_amd.EBelasticNet.Gaussian(X, y, float(d["lambda"]), float(d["alpha"]))
+    rep[name] = cmp_fit(out, d); rep[name]["wall_s"] = time.time() - t1; rep[name]["shape"] = list(X.shape)
+print(json.dumps(rep), flush=True)
+
+d = np.load(G + "/fulltest_looser19871.npz"); X, y = design(d)
+fid = AssignToFolds(X, 3, sample_kind="Rounding")
+a, l = BuildGrid(X, y, 3)
+# the stored Detail rows are (alpha, lambda, fold) in the run's own order: key them by value
+key = {}
+for f_, a_, l_, m_ in zip(d["detail_foldId"], d["detail_alpha"], d["detail_lambda"], d["detail_MSE"]):
+    key[(round(float(a_), 6), "%.6e" % l_, int(f_))] = m_
+want = np.array([[key[(round(float(a_), 6), "%.6e" % l_, f + 1)] for f in range(3)] for a_, l_ in zip(a, l)])
+ncell = int(os.environ.get("NCELL", "400"))
+sel = np.arange(400)[:ncell]
+t1 = time.time()
+with pareben_amd.Context(X, y, fid, 3) as ctx:
+    E, st, cnt = ctx.run(a[sel], l[sel])
+    timing = ctx.last_timing()
+rel = np.abs(E - want[sel]) / want[sel]
+r = {"shape": list(X.shape), "cells": int(ncell), "wall_s": time.time() - t1, "kernel_ms": timing,
+     "lambda_max_rel": float(abs(l.max() - d["detail_lambda"].max()) / l.max()),
+     "max_rel_finite": float(np.nanmax(rel)), "n_gt_1e-9": int((rel > 1e-9).sum()), "n_gt_1e-6": int((rel > 1e-6).sum()),
+     "status_hist": {str(int(s)): int((st == s).sum()) for s in np.unique(st)}, "max_active": int(cnt[..., 10].max())}
+bad = np.argwhere(~(rel <= 1e-9))
+r["deviating"] = [{"cell": int(sel[c]), "fold": int(f) + 1, "alpha": float(a[sel][c]), "lambda": float(l[sel][c]), "gpu": float(E[c, f]),
+                   "real_r": float(want[sel][c, f]), "rel": float(rel[c, f]), "m_max": int(cnt[c, f, 10]), "n_inner": int(cnt[c, f, 1]),
+                   "status": int(st[c, f])} for c, f in bad[:400]]
+print(json.dumps({k: v for k, v in r.items() if k != "deviating"}), flush=True)
+if ncell == 400 and np.isfinite(E).all(axis=1).any():
+    a_s, l_s, se, cv, idx = summarise_cv(a, l, E, 3)
+    r.update(alpha_opt=float(a_s[idx]), lambda_opt=float(l_s[idx]), cv_error=float(cv[idx]), r_alpha_opt=float(d["alpha_optimal"]),
+             r_lambda_opt=float(d["lambda_optimal"]),
+             rel_cv_error_at_optimum=float(abs(cv[idx] - d["summary_MSE"][idx]) / d["summary_MSE"][idx]),
+             max_rel_summary_mse=float(np.max(np.abs(cv - d["summary_MSE"]) / d["summary_MSE"])),
+             max_rel_summary_se=float(np.max(np.abs(se - d["summary_SE"]) / d["summary_SE"])))
+rep["looser19871_cv"] = r
+
+# EBENoutput_part1..3 (lambda = 2.195448, alpha = 0.5): which rows?  try the three training sets, the three held-out sets
+# and three contiguous thirds
+hyp = {}
+n = X.shape[0]
+third = [np.arange(n)[i * n // 3:(i + 1) * n // 3] for i in range(3)]
+for tag in ("part1", "part2", "part3"):
+    R = d[tag + "_weight"]
+    for hname, rows in ([("train%d" % f, np.where(fid != f)[0]) for f in (1, 2, 3)] + [("test%d" % f, np.where(fid == f)[0]) for f in (1, 2, 3)]
+                        + [("third%d" % (i + 1), third[i]) for i in range(3)] + [("all", np.arange(n))]):
+        try:
+            out = pareben_amd.EBelasticNet.Gaussian(np.asfortranarray(X[rows]), y[rows], float(d[tag + "_lambda"]), float(d[tag + "_alpha"]))
+        except pareben_amd.ParebenError as e:
+            hyp["%s_%s" % (tag, hname)] = {"error": str(e)}
+            continue
+        hyp["%s_%s" % (tag, hname)] = {"rows": int(out["weight"].shape[0]), "rows_r": int(R.shape[0]), "wald": float(out["WaldScore"]),
+                                       "wald_r": float(d[tag + "_WaldScore"]), "resid": float(out["residVar"]), "resid_r": float(d[tag + "_residVar"])}
+rep["parts"] = hyp
+rep["total_s"] = time.time() - t0
+out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "fulltest_probe.json")
+os.makedirs(os.path.dirname(out), exist_ok=True)
+json.dump(rep, open(out, "w"), indent=1)
+print(json.dumps({k: v for k, v in rep.items() if k != "parts"})[:6000])
