@@ -78,23 +78,25 @@ if ncell == 400 and np.isfinite(E).all(axis=1).any():
              max_rel_summary_se=float(np.max(np.abs(se - d["summary_SE"]) / d["summary_SE"])))
 rep["looser19871_cv"] = r
 
-# EBENoutput_part1..3 (lambda = 2.195448, alpha = 0.5): which rows?  try the three training sets, the three held-out sets
-# and three contiguous thirds
-hyp = {}
-n = X.shape[0]
-third = [np.arange(n)[i * n // 3:(i + 1) * n // 3] for i in range(3)]
-for tag in ("part1", "part2", "part3"):
-    R = d[tag + "_weight"]
-    for hname, rows in ([("train%d" % f, np.where(fid != f)[0]) for f in (1, 2, 3)] + [("test%d" % f, np.where(fid == f)[0]) for f in (1, 2, 3)]
-                        + [("third%d" % (i + 1), third[i]) for i in range(3)] + [("all", np.arange(n))]):
-        try:
-            out = pareben_amd.EBelasticNet.Gaussian(np.asfortranarray(X[rows]), y[rows], float(d[tag + "_lambda"]), float(d[tag + "_alpha"]))
-        except pareben_amd.ParebenError as e:
-            hyp["%s_%s" % (tag, hname)] = {"error": str(e)}
-            continue
-        hyp["%s_%s" % (tag, hname)] = {"rows": int(out["weight"].shape[0]), "rows_r": int(R.shape[0]), "wald": float(out["WaldScore"]),
-                                       "wald_r": float(d[tag + "_WaldScore"]), "resid": float(out["residVar"]), "resid_r": float(d[tag + "_residVar"])}
-rep["parts"] = hyp
+# EBENoutput_part1..3 (lambda = 2.195448, alpha = 0.5; no inputs named): PARTS=1 tries the three training sets, the three
+# held-out sets, three contiguous thirds and all rows (30 fits, 4 min) -- none reproduces them (profiles/r02/fulltest_probe.json)
+if os.environ.get("PARTS"):
+    hyp = {}
+    n = X.shape[0]
+    third = [np.arange(n)[i * n // 3:(i + 1) * n // 3] for i in range(3)]
+    for tag in ("part1", "part2", "part3"):
+        R = d[tag + "_weight"]
+        for hname, rows in ([("train%d" % f, np.where(fid != f)[0]) for f in (1, 2, 3)] + [("test%d" % f, np.where(fid == f)[0]) for f in (1, 2, 3)]
+                            + [("third%d" % (i + 1), third[i]) for i in range(3)] + [("all", np.arange(n))]):
+            try:
+                out = pareben_amd.EBelasticNet.Gaussian(np.asfortranarray(X[rows]), y[rows], float(d[tag + "_lambda"]), float(d[tag + "_alpha"]))
+            except pareben_amd.ParebenError as e:
+                hyp["%s_%s" % (tag, hname)] = {"error": str(e)}
+                continue
+            hyp["%s_%s" % (tag, hname)] = {"rows": int(out["weight"].shape[0]), "rows_r": int(R.shape[0]), "wald": float(out["WaldScore"]),
+                                           "wald_r": float(d[tag + "_WaldScore"]), "resid": float(out["residVar"]), "resid_r": float(d[tag + "_residVar"])}
+    rep["parts"] = hyp
+
 rep["total_s"] = time.time() - t0
 out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "fulltest_probe.json")
 os.makedirs(os.path.dirname(out), exist_ok=True)
