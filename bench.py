@@ -246,6 +246,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # a step of the large workloads runs for minutes without a word: a line on stderr every minute says the run is alive
+    # (rank 0 only; a sleeping Python thread, nothing in the timed path)
+    import threading
+    alive = threading.Event()
+    if rank == 0:
+        def heartbeat(t_start=time.perf_counter()):
+            while not alive.wait(60.0):
+                sys.stderr.write("bench.py: %s running, %.0f s\n" % (desc, time.perf_counter() - t_start)); sys.stderr.flush()
+        threading.Thread(target=heartbeat, daemon=True).start()
+
     t_first = None
     for w in range(args.warmup):
         t0 = time.perf_counter()
@@ -258,6 +268,7 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    alive.set()
     if t_first is None:                               # no warm-up: the first timed step was the cold one
         t_first = elapsed / args.steps
     if dist is not None:

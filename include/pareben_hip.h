@@ -73,7 +73,7 @@ int pareben_device_count(void);
  * Active-set capacity.  The reference sizes its arrays for basisMax = min(p, 1e7/p) columns
  * (elasticNetLinearNeMainEff.c:68-69; elasticNetLinearNeFull2.c:67-80 with epistasis) and runs off them when
  * a fit grows past that (:605-611: it prints "out of Memory" and continues).  Here such a fit is FLAGGED
- * (PAREBEN_ST_OVERFLOW) and continues in a workspace of max(basisMax, min(N_train, 1024)) columns (bounded by
+ * (PAREBEN_ST_OVERFLOW) and continues in a workspace of max(basisMax, min(N_train, 2048)) columns (bounded by
  * p and 2048); only there it is stopped (PAREBEN_ST_OVERFLOW | PAREBEN_ST_ABORT, score NaN).  max_active > 0
  * lowers both limits; <= 0 picks the defaults.  The context owns every device buffer.
  */

@@ -507,7 +507,7 @@ static int gm_inner(gm *s, int iter, double residual, double varY, double *cs, d
 /* Capacity policy.  Default = the reference's: the arrays hold basisMax columns and a fit that needs more is
  * stopped (the reference itself prints "out of Memory" and runs off its arrays, MainEff.c:605-611).  The HIP
  * build instead FLAGS such a fit (status bit 0) and lets it continue in a workspace of max(basisMax,
- * min(N, 1024)) columns; eben_set_capacity_policy(1, r) makes the oracle do the same so that those fits can be
+ * min(N, 2048)) columns; eben_set_capacity_policy(1, r) makes the oracle do the same so that those fits can be
  * compared too; r > 0 lowers basisMax to r (PAREBEN_REF_CAP on the other side), which brings the
  * flag-and-continue path within reach of small test problems. */
 static int g_continue_past_ref = 0, g_ref_cap_override = 0;
@@ -522,7 +522,7 @@ static void capacities(int ref_rule, long K, int N, int *cap_ref, int *cap)
     if (ref > K) ref = K;
     long c = ref;
     if (g_continue_past_ref) {
-        long lim = N < 1024 ? N : 1024;
+        long lim = N < 2048 ? N : 2048;
         if (lim > c) c = lim;
         if (c > K) c = K;
         if (c > 2048) c = 2048;

@@ -9,6 +9,9 @@
  *     paper_materials/Real Data Analysis/10000_Features/LooserSubset_10000_ParCV_5-3-2018.RDS (R 3.5.0 + CRAN
  *     EBEN) is reproduced to 1e-15 on every fit tried; tests/test_oracle_golden.py::test_oracle_reproduces_real_r_fit
  *     keeps one such fit in the suite.  The R-level pieces (grid, folds, summary) are pinned by the same file.
+ *     Second pin, whole fit outputs: the stored EBelasticNet.Gaussian results under paper_materials/Real Data
+ *     Analysis/Full_Test (R 3.5 + CRAN EBEN, Nov/Dec 2018) -- feature list, effects, posterior variances, WaldScore,
+ *     Intercept, residVar -- are reproduced to 2e-11 / 1e-14 (tests/test_oracle_golden.py::test_oracle_reproduces_real_r_refits).
  *   Gf (eben_gm.c with the epistasis variant), Bm and Bf (eben_bm.c): PARITY UNPINNED.  The reference tree holds no
  *     output of an epistasis or a binomial fit, its C cannot be built in this image (it needs R's headers and
  *     BLAS/LAPACK), and the known answers in SURVEY.md section 10 came from a build behind stand-in headers, which
@@ -39,7 +42,7 @@ typedef struct {
 } eben_counters;
 
 /* Capacity policy of the Gaussian fits (eben_gm.c): default (0, 0) = the reference's basisMax stops a fit;
- * (1, r) = flag (status bit 0) and continue up to max(basisMax, min(N, 1024)) like the HIP build, with
+ * (1, r) = flag (status bit 0) and continue up to max(basisMax, min(N, 2048)) like the HIP build, with
  * basisMax lowered to r when r > 0.  Process-wide; set before fitting. */
 void eben_set_capacity_policy(int continue_past_basismax, int ref_cap_override);
 

@@ -1485,13 +1485,14 @@ DEVNI int gm_spd_inverse_scalar(const Blk &B, const GmWork &W, int M)
 #ifndef INV_RUN
 #define INV_RUN 4          // tiles per run (multiple of INV_TT)
 #endif
-DEVNI int gm_spd_inverse_blocked(const Blk &B, const GmWork &W, int M, long long *phx)
+// TP: where the M x 16 panel Tn lives -- LDS while it fits (M <= 1040 with the 152 KB pool), else the fit's own
+// scratch in HBM (W.Tn, L2-resident: 2048 x 18 doubles = 295 KB); the two 16 x 17 pivot blocks are always in LDS.
+template <class TP>
+DEVNI int gm_spd_inverse_blocked(const Blk &B, const GmWork &W, int M, long long *phx, const TP Tn, const lptr_d nD)
 {
     const int ld = W.ld;
     const gptr_d Sig = as_global_rw(W.Sig);
     const int nT = (M + 15) >> 4, Mp = nT * 16;
-    const lptr_d Tn = as_lds(B.pool);
-    const lptr_d nD = Tn + (size_t)Mp * INV_TP;              // 16 x 17
     const lptr_d nD2 = nD + 16 * 17;                         // second copy for the pivot sweeps
     const int l15 = B.lane & 15, l4 = B.lane >> 4;
     for (int tk = 0; tk < nT; tk++) {
@@ -1639,7 +1640,11 @@ DEV int gm_spd_inverse(const Blk &B, const GmWork &W, int M, long long *phx = nu
     (void)phx;
 #ifndef PAREBEN_HOST_EMUL
     const int Mp = ((M + 15) >> 4) * 16;
-    if (M > 16 && Mp * INV_TP + 2 * 16 * 17 <= B.pool_n) return gm_spd_inverse_blocked(B, W, M, phx);
+    if (M > 16 && Mp * INV_TP + 2 * 16 * 17 <= B.pool_n) {
+        const lptr_d Tn = as_lds(B.pool);
+        return gm_spd_inverse_blocked(B, W, M, phx, Tn, Tn + (size_t)Mp * INV_TP);
+    }
+    if (M > 16 && W.Tn) return gm_spd_inverse_blocked(B, W, M, phx, as_global_rw(W.Tn), as_lds(B.pool));
 #endif
     return gm_spd_inverse_scalar(B, W, M);
 }
@@ -1674,7 +1679,7 @@ DEVNI int gm_final_update(const Blk &B, const FoldDev &F, const GmWork &W, int K
         const bool cached = S.gc_ok != 0;
         // the blocked inverse reads and writes only the triangle [j][i >= j] (and mirrors Sigma itself at the end);
         // the scattered mirror stores are needed only in front of the scalar inverse (M <= 16, or no LDS room)
-        const bool mirror = !(M > 16 && ((M + 15) >> 4) * 16 * INV_TP + 2 * 16 * 17 <= B.pool_n);
+        const bool mirror = !(M > 16 && (((M + 15) >> 4) * 16 * INV_TP + 2 * 16 * 17 <= B.pool_n || W.Tn));
         for (int j = B.wave; j < M; j += B.nwave) {
             const size_t rj = (size_t)lr[j] * K;
             // Phi_i.Phi_j from the Gram matrix: element (j, i >= j) is G[row_j][used_i] -- gathered from Gram row j

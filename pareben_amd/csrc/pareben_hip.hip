@@ -267,7 +267,7 @@ static WsLayout ws_layout(int K, int cap)
     L.cap = cap; L.ld = (cap + 15) / 16 * 16;      // whole 16-row blocks: the matrix-core passes index rows without clamps
     size_t o = 0;
     L.offK = o;   o += align_up((size_t)K * (7 * sizeof(double) + 2 * sizeof(int) + 1), 256);
-    L.offSig = o; o += align_up((size_t)3 * L.ld * L.ld * sizeof(double), 256);      // Sigma, H, Gram block cache
+    L.offSig = o; o += align_up(((size_t)3 * L.ld * L.ld + (size_t)L.ld * INV_TP) * sizeof(double), 256);      // Sigma, H, Gram block cache, inverse panel
     L.offM = o;   o += align_up((size_t)(cap + 2) * ((7 + ADD_TB) * sizeof(double) + 3 * sizeof(int)) + 4 * ADD_TB * sizeof(double), 256);
     L.bytes = align_up(o, 4096);
     return L;
@@ -284,7 +284,7 @@ __device__ inline GmWork ws_carve(char *base, int K, int cap, size_t offK, size_
     W.act = (signed char *)ip;
     d = (double *)(base + offSig);
     const int ldp = (cap + 15) / 16 * 16;
-    W.Sig = d; d += (size_t)ldp * ldp; W.H = d; d += (size_t)ldp * ldp; W.Gc = d;
+    W.Sig = d; d += (size_t)ldp * ldp; W.H = d; d += (size_t)ldp * ldp; W.Gc = d; d += (size_t)ldp * ldp; W.Tn = d;
     d = (double *)(base + offM);
     const int c1 = cap + 1;
     W.A = d; d += c1; W.mu = d; d += c1; W.gam = d; d += c1;
@@ -366,7 +366,7 @@ struct CvParams {
 // LDS carve of one fit workgroup (dynamic shared memory): a phase-local pool (full-stat Gram
 // k-blocks and Sigma panels / inverse panels / action vectors) and the small reduction scratch.
 #ifndef LDS_POOL_DOUBLES
-#define LDS_POOL_DOUBLES 19456    // 152 KB of the CU's 160 KB: the blocked inverse keeps its M x 16 panel (pitch 18) in it up to M = 1040
+#define LDS_POOL_DOUBLES 19456    // 152 KB of the CU's 160 KB: the blocked inverse keeps its M x 16 panel (pitch 18) in it up to M = 1040 (beyond: GmWork::Tn)
 #endif
 #define LDS_FIT_BYTES ((LDS_POOL_DOUBLES + 2 * BLK_MAX_WAVES) * 8 + 4 * BLK_MAX_WAVES * 4)
 extern __shared__ double lds_dyn[];
@@ -757,17 +757,22 @@ struct pareben_ctx {
 // (elasticNetLinearNeMainEff.c:68-69; elasticNetLinearNeFull2.c:67-80 for epistasis) and, when a fit grows
 // past that, prints "out of Memory" and keeps writing (:605-611) -- undefined behaviour, at K = 50 000 already
 // from 200 columns on.  Policy here: `cap_ref` is that number and only FLAGS a fit (PAREBEN_ST_OVERFLOW);
-// the fit goes on in a workspace of `cap` >= cap_ref columns, cap = max(cap_ref, min(N_train, 1024)) bounded
-// by K and by what the matrix-core passes are laid out for, and is stopped (ST_OVERFLOW | ST_ABORT, score
-// NaN) only there.  An active set larger than the number of training rows is not a model the algorithm
-// keeps (delete priority from M >= N on), so min(N_train, .) costs nothing; 1024 bounds the workspace
-// (3 x cap^2 doubles per resident fit).  max_active > 0 (ctx_create) lowers both; PAREBEN_REF_CAP=<n> lowers
-// cap_ref alone (tests: the flag-and-continue path at sizes the oracle can follow).
+// the fit goes on in a workspace of `cap` >= cap_ref columns, cap = max(cap_ref, min(N_train, 2048)) bounded
+// by K and by what the matrix-core passes are laid out for (FS_MAX_M), and is stopped (ST_OVERFLOW | ST_ABORT,
+// score NaN) only there.  An active set larger than the number of training rows is not a model the algorithm
+// keeps (delete priority from M >= N on), so min(N_train, .) costs nothing.  The workspace is 3 x cap^2 doubles per
+// resident fit (100 MB at 2048 columns, 26 GB for 256 workgroups: the Gram planner in ctx_create counts it).
+// Real data needs the room: on the reference's own 3802 x 19 871 design every fit of one fold passes 1024 columns
+// within seven inner iterations (batch adds) and peaks at 1067 ... 1451 before the deletes bring it back to ~200.
+// max_active > 0 (ctx_create) lowers both; PAREBEN_WS_CAP=<cols> lowers the workspace bound and PAREBEN_REF_CAP=<n>
+// cap_ref alone (tests: the stop and the flag-and-continue paths at sizes the oracle can follow).
 static void capacities(int K, int ref_rule, int n_train_max, int max_active, int *cap_ref_out, int *cap_out)
 {
     long ref = ref_rule;
     if (ref > K) ref = K;
-    long cap = std::max<long>(ref, std::min(n_train_max, 1024));
+    long ws = FS_MAX_M;
+    if (const char *e = getenv("PAREBEN_WS_CAP")) { const long v = atol(e); if (v >= 2 && v < ws) ws = v; }
+    long cap = std::max<long>(ref, std::min<long>(n_train_max, ws));
     if (cap > K) cap = K;
     if (cap > FS_MAX_M) cap = FS_MAX_M;
     if (max_active > 0 && cap > max_active) cap = max_active;

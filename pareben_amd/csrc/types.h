@@ -61,6 +61,7 @@ struct GmWork {
     signed char *act;                                      // K
     double *Sig, *H;                                       // cap x cap, column-major, ld = cap
     double *Gc;        // device only: Gram block of the active set, Gc[j][i] = G[row_j][used_i] for slots j <= i (gm_final_update)
+    double *Tn = nullptr;   // device only: ld x 18 scratch for the blocked inverse's pivot-column panel when it does not fit in LDS (M > 1040)
     double *A, *mu, *gam, *v1, *v2, *v3, *v4;              // cap+1 each
     double *vb, *bsc;                                      // batched adds: ADD_TB vectors of cap+2, 4*ADD_TB scalars
     int *used;                                             // cap+1  feature of each active slot

@@ -300,7 +300,7 @@ def test_epistasis_vs_golden(golden):
         E2, st, cnt = ctx.run(g["alpha_scaled"], g["lam_scaled"])
     # the reference's basisMax here is 2K = 120: the fixture (oracle with the reference's policy) has no score for
     # the small-lambda fits that need more; the HIP path flags those (bit 0) and lets them continue to
-    # min(N_train, 1024) = 160 columns -- compared in test_flag_and_continue_past_reference_capacity
+    # min(N_train, 2048) = 160 columns -- compared in test_flag_and_continue_past_reference_capacity
     ref = g["fold_err_scaled"]
     ok = (st & 9) == 0
     assert ok.mean() > 0.3
@@ -321,7 +321,7 @@ def test_flag_and_continue_past_reference_capacity(golden, oracle, monkeypatch):
     with pareben_amd.Context(X, y, fid, 3) as ctx:
         E, st, cnt = ctx.run(alpha[sel], lam[sel])
         info = ctx.launch_info()
-    assert info["reference_capacity"] == 12 and info["capacity"] == 200        # max(basisMax = K = 200, min(N_train, 1024))
+    assert info["reference_capacity"] == 12 and info["capacity"] == 200        # max(basisMax = K = 200, min(N_train, 2048))
     oracle.set_capacity_policy(True, 12)
     try:
         Eo, co, rc = oracle.cv_grid(X, y, fid, 3, alpha[sel], lam[sel])
@@ -579,7 +579,7 @@ def test_config5_full_size_properties():
     ten 20 GB Gram matrices resident in HBM), on twelve cells spread over the lambda range (120 fits; the whole
     grid is `bench.py --workload config5`, 40 000 fits, profiles/r02/).  The oracle cannot follow at this size, so
     size-independent properties: every score finite (the reference's basisMax = 1e7/p = 200 only flags a fit
-    here; the workspace holds 1024 columns), null-model bound at the largest lambda, informative cells beat the
+    here; the workspace holds min(N_train, 2048) = 1800 columns), null-model bound at the largest lambda, informative cells beat the
     null model, target-shift invariance, bit-identical rerun in another order."""
     from pareben_amd.synth import synthetic_gaussian as bench_design
     n, p, nf = 2000, 50000, 10
@@ -595,7 +595,7 @@ def test_config5_full_size_properties():
         info = ctx.launch_info()
         perm = np.random.default_rng(5).permutation(len(sel))
         E2, st2, _ = ctx.run(alpha[sel][perm], lam[sel][perm])
-    assert info["reference_capacity"] == 200 and info["capacity"] == 1024
+    assert info["reference_capacity"] == 200 and info["capacity"] == 1800
     assert np.all((st & 8) == 0) and np.all(np.isfinite(E)) and np.all(E > 0)
     assert ((st & 1) != 0).sum() > 0 and cnt[..., 10].max() > 200       # fits the reference would have run off its arrays with
     assert np.array_equal(E2, E[perm]) and np.array_equal(st2, st[perm])
@@ -606,3 +606,31 @@ def test_config5_full_size_properties():
     with pareben_amd.Context(X, y + 3.0, fid, nf) as ctx:
         Es, _, _ = ctx.run(alpha[sel][spot], lam[sel][spot])
     assert _rel(Es, E[spot]).max() < 1e-6
+
+
+def test_active_sets_beyond_1024_columns():
+    """Two single fits whose active sets peak at 1087 and 1239 columns (synthetic n = 3000, p = 4500, lambda =
+    1e-5 lambda_max, alpha = 0.05 and 1; the reference's own basisMax there is 1e7/4500 = 2222, so these are fits the
+    reference handles, not flag-and-continue cases) against the oracle (tools/make_big_m_oracle.py, ~20 CPU-minutes each).
+    Past 1040 columns the blocked inverse's pivot-column panel lives in the fit's HBM scratch instead of LDS
+    (gm_spd_inverse_blocked<global>), and the full-stat pass runs its 16-row blocks up to FS_MAX_M = 2048: the same
+    add / delete / re-estimate sequence, the same model, effects to 1e-7."""
+    import os
+    from pareben_amd.synth import synthetic_gaussian
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "big_m_oracle.npz"))
+    X, y, _, _ = synthetic_gaussian(int(g["n"]), int(g["p"]))
+    for i in (0, 1):
+        pre = "c%d_" % i
+        want = dict(zip([str(k) for k in g[pre + "counter_names"]], [int(v) for v in g[pre + "counters"]]))
+        r = pareben_amd.fit_gaussian(X, y, float(g[pre + "lambda"]), float(g[pre + "alpha"]))
+        c = r["counters"]
+        assert c["status"] == 0 and c["m_max"] > 1040
+        for k in ("n_outer", "n_inner", "n_add", "n_del", "n_reest", "n_fullstat", "m_final", "m_max", "sum_m_action"):
+            assert c[k] == want[k], (k, c[k], want[k])
+        b, bo = r["Beta"][:, 2], g[pre + "beta"]
+        assert np.array_equal(b != 0, bo != 0)
+        nz = bo != 0
+        assert _rel(b[nz], bo[nz]).max() < 1e-7 and _rel(r["Beta"][nz, 3], g[pre + "var"][nz]).max() < 1e-7
+        assert abs(r["wald"] - float(g[pre + "wald"])) < 1e-9 * abs(r["wald"])
+        assert abs(r["residual"] - float(g[pre + "residual"])) < 1e-9 * r["residual"]
+        assert abs(r["intercept"] - float(g[pre + "intercept"])) < 1e-7 * max(abs(r["intercept"]), 1e-3)

@@ -120,12 +120,14 @@ def test_stored_refits_vs_real_r(fulltest):
         _same_fit(out, d, "", X.shape[0])
 
 
-def test_looser19871_cell_vs_oracle(fulltest):
+def test_looser19871_cell_vs_oracle(fulltest, monkeypatch):
     """The largest design the reference tree holds (Full_Test/filter_matrix_looser_0.02_main_0.15_epi: 3802 x 19 871 as the
     authors' runs saw it), cell 1 of its 3-fold grid (alpha = 0.95, lambda = lambda_max): HIP path against the oracle's
     values (tools/make_looser19871_oracle.py, 19 CPU-minutes; 1061 and 3323 inner iterations, active sets up to 514 --
-    past the reference's basisMax = 503 in fold 3, which both sides flag and continue).  Fold 2 needs more than the
-    1024-column workspace on this design: stopped and reported on the device.  (The real-R table stored for this
+    past the reference's basisMax = 503 in fold 3, which both sides flag and continue).  Fold 2 peaks above 1024 columns
+    on this design; the fixture was computed with a 1024-column workspace, so PAREBEN_WS_CAP = 1024 here and the fit
+    must come back stopped and reported (the default 2048-column workspace completes it:
+    test_active_sets_beyond_1024_columns).  (The real-R table stored for this
     design, parEBENoutput_2018-08-15*.RDS, is not reproducible from the tree -- DESIGN.md section 7 -- so this case
     is checked against the oracle only; its lambda grid is checked against the stored one.)"""
     import json, os
@@ -137,8 +139,10 @@ def test_looser19871_cell_vs_oracle(fulltest):
     assert a[1] == o["alpha"] and abs(l[1] - o["lambda"]) <= 1e-14 * l[1]
     assert np.allclose(np.unique(l), np.unique(d["detail_lambda"]), rtol=1e-13, atol=0)      # real R's grid
     fid = AssignToFolds(X, 3, sample_kind="Rounding")
+    monkeypatch.setenv("PAREBEN_WS_CAP", "1024")
     with pareben_amd.Context(X, y, fid, 3) as ctx:
         E, st, cnt = ctx.run(np.array([o["alpha"]]), np.array([o["lambda"]]))
+        assert ctx.launch_info()["capacity"] == 1024
     want = np.array(o["fold_sse"])
     assert st[0, 0] == 0 and st[0, 2] == 1 and st[0, 1] & 8 and np.isnan(E[0, 1])
     for f in (0, 2):
