@@ -592,6 +592,8 @@ struct FitParams {
     int K, cap, cap_flag;
     int p;               // design columns (K = p without epistasis)
     GmVariant v;
+    // helper workgroups (blocks 1..): the job board of the shared phases; null = the fit runs alone
+    FsJob *jobs; int *active; int *queue; const FoldDev *folds; size_t ws_stride;
 };
 
 // single Gaussian fit with the reference's .C outputs: elasticNetLinearNeMainEff.c:199-227 (Beta K x 4:
@@ -602,6 +604,14 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_EU) void gm_fit_kernel(F
     __shared__ FitCounters s_cnt;
     __shared__ long long s_ph[PH_N];
     const Blk B = make_blk();
+    // One fit = one workgroup, as in the CV kernel; the other workgroups of the launch only lend a hand with its
+    // feature-parallel phases (full-stat passes, action sweeps) through the same job board and leave when the
+    // owner is done (`active`, set to 1 by the host, drops to 0).  Bit-identical with or without them.
+    FsShare sh;
+    sh.jobs = P.jobs; sh.active = P.active; sh.queue = P.queue; sh.n_units = 1; sh.n_blocks = gridDim.x;
+    sh.self = blockIdx.x; sh.ws = P.ws; sh.ws_stride = P.ws_stride; sh.offK = P.offK; sh.offSig = P.offSig; sh.offM = P.offM;
+    sh.folds = P.folds; sh.cap = P.cap; sh.early = 1; sh.heavy_m = 0;
+    if (blockIdx.x > 0) { fs_help_loop(B, sh, P.K, true); return; }
     GmWork W = ws_carve(P.ws, P.K, P.cap, P.offK, P.offSig, P.offM);
     W.cap_flag = P.cap_flag;
     const int K = P.K, p = P.p;
@@ -618,7 +628,9 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_EU) void gm_fit_kernel(F
     S.c = &s_cnt;
     S.ph = s_ph;
     S.v = P.v;
+    if (P.jobs) { S.share = &sh; S.fold = 0; }
     gm_fit(B, P.F, W, K, P.lambda, P.alpha, S);
+    if (threadIdx.x == 0 && P.active) AT_ADD(P.active, -1);        // the helpers may go (every path of the owner gets here)
     const int M = S.M, ld = W.ld;
     PAR(i, M) {
         const int f = W.used[i];
@@ -1453,7 +1465,8 @@ static int fit_one(int prior, int epis, const double *basis, const double *targe
     const int ncol = (epis && prior == PAREBEN_PRIOR_GAUSSIAN) ? 5 : 4;
     const size_t KF = (epis && prior == PAREBEN_PRIOR_BINOMIAL) ? (size_t)2 * k : (size_t)c->kfull;     // rows of the Beta table
     double *d_beta = nullptr, *d_sc = nullptr; int *d_st = nullptr; long long *d_cnt = nullptr;
-    auto cleanup = [&]() { hipFree(d_beta); hipFree(d_sc); hipFree(d_st); hipFree(d_cnt); };
+    FsJob *d_jobs = nullptr; int *d_flags = nullptr;
+    auto cleanup = [&]() { hipFree(d_beta); hipFree(d_sc); hipFree(d_st); hipFree(d_cnt); hipFree(d_jobs); hipFree(d_flags); };
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return bail(fail(PAREBEN_EHIP, #x, e_)); } } while (0)
     CK(dmalloc(&d_beta, KF * ncol)); CK(dmalloc(&d_sc, (size_t)4)); CK(dmalloc(&d_st, (size_t)1));
     CK(dmalloc(&d_cnt, (size_t)PAREBEN_NCOUNTERS));
@@ -1466,7 +1479,23 @@ static int fit_one(int prior, int epis, const double *basis, const double *targe
         P.ws = c->d_ws; P.offK = c->L.offK; P.offSig = c->L.offSig; P.offM = c->L.offM; P.K = c->kfull; P.cap = c->cap; P.cap_flag = c->cap_ref;
         P.p = k; P.v = c->variant;
         CK(hipFuncSetAttribute((const void *)gm_fit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FIT_BYTES));
-        hipLaunchKernelGGL(gm_fit_kernel, dim3(1), dim3(FIT_THREADS), LDS_FIT_BYTES, c->stream, P);
+        // helpers: as many workgroups as are resident at once (they wait for the owner, so none may be left undispatched
+        // in front of it); PAREBEN_SHARE=0 runs the fit alone
+        int blocks = 1;
+        const char *share_env = getenv("PAREBEN_SHARE");
+        P.jobs = nullptr; P.active = nullptr; P.queue = nullptr; P.folds = c->d_folds; P.ws_stride = c->L.bytes;
+        if (!(share_env && atoi(share_env) == 0)) {
+            int occ = 1;
+            CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, gm_fit_kernel, FIT_THREADS, LDS_FIT_BYTES));
+            blocks = std::max(1, c->n_cu * std::max(occ, 1));
+            CK(dmalloc(&d_jobs, (size_t)blocks)); CK(dmalloc(&d_flags, (size_t)8));
+            CK(hipMemsetAsync(d_jobs, 0, sizeof(FsJob) * (size_t)blocks, c->stream));
+            const int flags[8] = {1, 0, 0, 0, 1, 0, 0, 0};          // [0] active: the owner holds its fit; [4] queue head = n_units: drained
+            CK(hipMemcpyAsync(d_flags, flags, sizeof flags, hipMemcpyHostToDevice, c->stream));
+            CK(hipStreamSynchronize(c->stream));                     // `flags` is a stack array
+            P.jobs = d_jobs; P.active = d_flags; P.queue = d_flags + 4;
+        }
+        hipLaunchKernelGGL(gm_fit_kernel, dim3(blocks), dim3(FIT_THREADS), LDS_FIT_BYTES, c->stream, P);
     } else {
         BmFitParams P;
         P.F = F; P.lambda = lambda; P.alpha = alpha; P.Beta = d_beta; P.scalars = d_sc; P.status = d_st; P.counters = d_cnt;

@@ -125,3 +125,18 @@ def test_binomial_epistasis_refit_vs_oracle(golden, oracle):
         main = w[w[:, 0] == w[:, 1]]; pair = w[w[:, 0] != w[:, 1]]
         assert np.array_equal(w, np.vstack([main, pair])) and np.all(np.diff(main[:, 0]) >= 0) and np.all(np.diff(pair[:, 0]) >= 0)
         assert np.allclose(w[:, 4], np.abs(w[:, 2]) / (np.sqrt(w[:, 3]) + 1e-20))
+
+
+@pytest.mark.gpu
+def test_refit_helper_workgroups_bit_identical(fulltest, monkeypatch):
+    """A single Gaussian fit is one workgroup; the other workgroups of `gm_fit_kernel`'s launch take chunks of its
+    full-stat passes and action sweeps through the CV kernel's job board (3843 x 11 597: 2.3 s alone, 0.9 s with
+    help; 3802 x 19 871: 18.5 -> 4.2 s, profiles/r02/refit_time.txt).  Same bits either way."""
+    X, y, d = fulltest("zeo_main_epi")
+    lam, al = float(d["lambda"]), float(d["alpha"])
+    helped = pareben_amd.fit_gaussian(X, y, lam, al)
+    monkeypatch.setenv("PAREBEN_SHARE", "0")
+    alone = pareben_amd.fit_gaussian(X, y, lam, al)
+    assert np.array_equal(helped["Beta"], alone["Beta"])
+    assert helped["wald"] == alone["wald"] and helped["intercept"] == alone["intercept"] and helped["residual"] == alone["residual"]
+    assert helped["counters"] == alone["counters"] and helped["counters"]["n_inner"] > 1000
