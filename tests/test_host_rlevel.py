@@ -92,3 +92,37 @@ def test_summary_binomial_intent():
     a_s, l_s, se, err, idx = summarise_cv(alpha, lam, E, 2, prior="binomial")
     assert np.allclose(err, [0.45, 0.65]) and a_s[idx] == 0.5
     assert abs(r_sd([1.0, 2.0, 4.0]) - 1.5275252316519468) < 1e-15
+
+
+def test_local_search_policy_matches_real_r_output(fulltest):
+    """The host policy of search = "local" (pareben_amd/local.py, R/LocalSearch.R:52-134) against a real-R output:
+    Full_Test/parEBENoutput_epi0.08_residual_cv3local*.RDS = CrossValidate(search = "local", nFolds = 3) on
+    filter_matrix_epi0.08 + pheno_Zeo_residual.  Its fold errors cannot be recomputed (that run drew its folds with an
+    unseeded sample(), R/LocalSearch.R:13-20), but the policy can be replayed over R's own per-cell (mean, SE): same
+    lambda grid, same walk (all 400 cells: no early stop fires with SEs of ~10 on differences of ~1), same fullCV rows in
+    the same order, same per-alpha minima table and the same (alpha.optimal, lambda.optimal) = (0.05, 0.6625895...)."""
+    from pareben_amd.local import replay_local_search
+    X, y, d = fulltest("epi008")
+    C, F = d["local_CrossValidation"], d["local_fullCV"]
+    alpha, lam = BuildGrid(X, y, 3)
+    a_desc, l_desc = np.unique(alpha)[::-1], np.unique(lam)[::-1]
+    assert np.allclose(a_desc, F[::20, 0], rtol=0, atol=1e-15) and np.allclose(l_desc, F[:20, 1], rtol=1e-13, atol=0)
+    mean = F[:, 2].reshape(20, 20); se = F[:, 3].reshape(20, 20)
+
+    def folds_of(ia, il):                      # three fold errors with exactly this mean and sd/sqrt(3)
+        c = se[ia, il] * math.sqrt(3.0)
+        return [mean[ia, il] - c, mean[ia, il], mean[ia, il] + c]
+    each, a_opt, l_opt, msecv, visited = replay_local_search(a_desc, l_desc, folds_of)
+    assert len(visited) == 400
+    assert np.allclose(msecv[:, 2:], F[:, 2:], rtol=1e-12, atol=0) and np.allclose(msecv[:, :2], F[:, :2], rtol=1e-13, atol=1e-15)
+    assert np.allclose(each, C, rtol=1e-12, atol=1e-15)
+    assert abs(a_opt - float(d["local_alpha_optimal"])) < 1e-15 and abs(l_opt - float(d["local_lambda_optimal"])) <= 1e-13 * l_opt
+    # and an early stop, which this table never takes: raise one cell of alpha = 1 by more than its predecessor's SE
+    mean2 = mean.copy(); mean2[0, 3] = mean[0, :3].min() + se[0, int(np.argmin(mean[0, :3]))] + 1.0
+
+    def folds2(ia, il):
+        c = se[ia, il] * math.sqrt(3.0)
+        return [mean2[ia, il] - c, mean2[ia, il], mean2[ia, il] + c]
+    each2, _, _, msecv2, visited2 = replay_local_search(a_desc, l_desc, folds2)
+    assert [v for v in visited2 if v[0] == 0] == [(0, 0), (0, 1), (0, 2), (0, 3)] and len(visited2) == 400 - 16
+    assert np.all(msecv2[len(visited2):] == 0) and each2[0, 1] == l_desc[int(np.argmin(mean2[0, :4]))]
