@@ -101,12 +101,13 @@ def _same_fit(out, d, pre, N):
 
 
 def test_stored_refits_vs_real_r(fulltest):
-    """`pareben_fit_gaussian` behind EBelasticNet.Gaussian against the five real-R fit outputs the reference keeps under
-    paper_materials/Real Data Analysis/Full_Test (R 3.5 + CRAN EBEN, Nov/Dec 2018), on their own inputs: the complete
+    """`pareben_fit_gaussian` behind EBelasticNet.Gaussian against seven real-R fit outputs the reference keeps under
+    paper_materials/Real Data Analysis/Full_Test (R 3.5 + CRAN EBEN, Aug - Dec 2018), on their own inputs: the complete
     `weight` table incl. the t and p columns (R/EBelasticNet.Gaussian.R:84-98), WaldScore, Intercept, residVar.
       EBENoutput_epi0.08_residual*.RDS (3)   3843 x 201,    109 features
       EBENoutput_Zeo_2018-11-20*.RDS         3843 x 11 396, 324 features, lambda 0.4263464, alpha 0.8
       EBENoutput_epi0.08_2018-12-02*.RDS     3843 x 11 597, 251 features, lambda 0.296393,  alpha 0.9
+      EBENoutput_part1 / part2*.RDS          3802 x 13 248 / 13 247, 312 / 122 features, lambda 2.195448, alpha 0.5
     Same features, effects to 1e-10, Wald score to 1e-14 (4 s and 2.3 s for the two large ones incl. staging)."""
     X, y, d = fulltest("epi008")
     for tag in "abc":
@@ -118,6 +119,14 @@ def test_stored_refits_vs_real_r(fulltest):
         out = pareben_amd.EBelasticNet.Gaussian(X, y, float(d["lambda"]), float(d["alpha"]))
         assert out["weight"].shape[0] == rows
         _same_fit(out, d, "", X.shape[0])
+    # EBENoutput_part1 / part2 (2018-08-16, lambda = 2.195448, alpha = 0.5: the optimum of the previous day's CV run on the
+    # 19 871-column design): the files name no inputs; they are the fits on that design's first 13 248 and last 13 247
+    # columns (tools/parts_probe.py found them; part3 is not identified).  312 and 122 features.
+    X, y, d = fulltest("looser19871")
+    for tag, cols, rows in (("part1", slice(0, 13248), 312), ("part2", slice(6624, 19871), 122)):
+        out = pareben_amd.EBelasticNet.Gaussian(np.asfortranarray(X[:, cols]), y, float(d[tag + "_lambda"]), float(d[tag + "_alpha"]))
+        assert out["weight"].shape[0] == rows
+        _same_fit(out, d, tag + "_", X.shape[0])
 
 
 def test_looser19871_cell_vs_oracle(fulltest, monkeypatch):
