@@ -608,7 +608,7 @@ def test_config5_full_size_properties():
     assert _rel(Es, E[spot]).max() < 1e-6
 
 
-def test_active_sets_beyond_1024_columns():
+def test_active_sets_beyond_1024_columns(monkeypatch):
     """Two single fits whose active sets peak at 1087 and 1239 columns (synthetic n = 3000, p = 4500, lambda =
     1e-5 lambda_max, alpha = 0.05 and 1; the reference's own basisMax there is 1e7/4500 = 2222, so these are fits the
     reference handles, not flag-and-continue cases) against the oracle (tools/make_big_m_oracle.py, ~20 CPU-minutes each).
@@ -634,3 +634,7 @@ def test_active_sets_beyond_1024_columns():
         assert abs(r["wald"] - float(g[pre + "wald"])) < 1e-9 * abs(r["wald"])
         assert abs(r["residual"] - float(g[pre + "residual"])) < 1e-9 * r["residual"]
         assert abs(r["intercept"] - float(g[pre + "intercept"])) < 1e-7 * max(abs(r["intercept"]), 1e-3)
+    # the HBM panel of the inverse and the 16-row pad bands up to 1088 columns do not depend on what the workspace held
+    monkeypatch.setenv("PAREBEN_WS_POISON", "1")
+    r2 = pareben_amd.fit_gaussian(X, y, float(g["c1_lambda"]), float(g["c1_alpha"]))
+    assert np.array_equal(r2["Beta"], r["Beta"]) and r2["wald"] == r["wald"] and r2["counters"] == r["counters"]
