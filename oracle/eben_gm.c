@@ -522,7 +522,9 @@ static void capacities(int ref_rule, long K, int N, int *cap_ref, int *cap)
     if (ref > K) ref = K;
     long c = ref;
     if (g_continue_past_ref) {
-        long lim = N < 2048 ? N : 2048;
+        long ws = 2048;                          /* EBEN_ORACLE_WS_CAP=<cols>: the other side's PAREBEN_WS_CAP */
+        { const char *e = getenv("EBEN_ORACLE_WS_CAP"); if (e && atol(e) >= 2 && atol(e) < ws) ws = atol(e); }
+        long lim = N < ws ? N : ws;
         if (lim > c) c = lim;
         if (c > K) c = K;
         if (c > 2048) c = 2048;

@@ -1,7 +1,10 @@
 """tests/golden/looser19871_oracle_cell1.json: the oracle's fold SSEs of cell 1 (alpha = 0.95, lambda = lambda_max) of the
 3-fold grid on the 19871-column Full_Test design (tests/golden/fulltest_looser19871.npz), flag-and-continue capacity
-policy.  19 CPU-minutes (three threads, one per fold); the GPU test test_looser19871_cell_vs_oracle compares with it."""
+policy with a 1024-column workspace (EBEN_ORACLE_WS_CAP / PAREBEN_WS_CAP = 1024: fold 2 peaks above that and is cut short
+there on both sides; with the default 2048 columns the oracle would need hours for it).  19 CPU-minutes (three threads,
+one per fold); the GPU test test_looser19871_cell_vs_oracle compares with it."""
 import json, os, sys, time
+os.environ["EBEN_ORACLE_WS_CAP"] = "1024"
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
