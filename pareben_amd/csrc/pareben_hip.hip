@@ -1025,12 +1025,14 @@ static int run_enqueue(pareben_ctx *c, int n_cells, const double *alpha, const d
     HIPCHK(hipSetDevice(c->device));
     const int nF = c->n_folds, n_units = n_cells * nF;
     // Queue order.  Cost is far from monotone in lambda: nothing happens above the lambda where the first
-    // features enter, the heaviest fits sit right at that sparse-to-dense transition (its position moves
-    // with alpha), and below it the cost is flat -- except for the occasional very long add/delete
-    // trajectory at the smallest lambdas.  So the queue runs outside-in over the lambda-sorted cells,
-    // three cells from the large-lambda end for each one from the small-lambda end: the large end is
-    // consumed almost for free and reaches the transition early, the small end starts its long fits
-    // at once, and the uniform middle packs the tail.
+    // features enter (a third of the grid costs nothing), the heaviest fits -- seconds each, against a mean of
+    // 0.2 s -- sit right below it at the sparse-to-dense transition (its position moves with alpha), and from there
+    // down the cost is flat.  So the queue simply runs from the large-lambda end: the free cells fly by, the heavy
+    // ridge starts within the first milliseconds, and the uniform plateau packs the tail.  (Until the end of round 2
+    // one cell in four was taken from the small-lambda end instead; measured on rank shares of config 2 the plain
+    // descending order is as fast on a full grid -- 7.98 vs 7.99 s -- and better when a launch holds few fits per
+    // workgroup, where a late heavy fit is the critical path: 4.40 -> 4.20 s for a half grid, 2.88 -> 2.67 s for a
+    // quarter.  PAREBEN_QUEUE_MIX=<n> brings the interleave back for A/B runs.)
     std::vector<int> sorted(n_cells), cells(n_cells);
     std::iota(sorted.begin(), sorted.end(), 0);
     std::stable_sort(sorted.begin(), sorted.end(), [&](int a, int b) {
@@ -1041,10 +1043,10 @@ static int run_enqueue(pareben_ctx *c, int n_cells, const double *alpha, const d
     // from the small-lambda end -- longest first, the short ones pack the tail (config 3: 8 % shorter than outside-in)
     const char *qenv = getenv("PAREBEN_QUEUE");                 // A/B: "outside-in" | "small-first"
     const bool small_first = qenv ? !strcmp(qenv, "small-first") : c->prior == PAREBEN_PRIOR_BINOMIAL;
-    const char *menv = getenv("PAREBEN_QUEUE_MIX");             // A/B: one cell from the small-lambda end per <n> (default 4)
-    const int qmix = (menv && atoi(menv) >= 2) ? atoi(menv) : 4;
+    const char *menv = getenv("PAREBEN_QUEUE_MIX");             // A/B: one cell from the small-lambda end per <n> (default: none)
+    const int qmix = (menv && atoi(menv) >= 2) ? atoi(menv) : 0;       // 0: none from the small end
     for (int k = 0, lo = 0, hi = n_cells - 1; k < n_cells; k++)
-        cells[k] = small_first ? sorted[n_cells - 1 - k] : (((k % qmix) == qmix - 1) ? sorted[hi--] : sorted[lo++]);
+        cells[k] = small_first ? sorted[n_cells - 1 - k] : ((qmix && (k % qmix) == qmix - 1) ? sorted[hi--] : sorted[lo++]);
     D.order.resize(n_units);
     for (int k = 0; k < n_cells; k++) for (int f = 0; f < nF; f++) D.order[k * nF + f] = cells[k] * nF + f;
 
