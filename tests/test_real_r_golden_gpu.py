@@ -88,6 +88,49 @@ def test_full_table_vs_real_r(golden, yeast):
     assert d_mse.max() <= fx["max_rel_diff_summary_mse"] * 1.0001 + 1e-12 and d_se.max() <= fx["max_rel_diff_summary_se"] * 1.0001 + 1e-12
 
 
+def test_second_table_vs_real_r(fulltest):
+    """The second real-R CrossValidate() table the reference holds: Full_Test/parEBENoutput_2018-08-15*.RDS (R 3.5 + CRAN
+    EBEN, doMPI; 3 folds x 400 cells, pheno1).  It names no inputs; it is the run on the first 13 248 columns of
+    filter_matrix_looser_0.02_main_0.15_epi (tools/cv19871_prefix_probe.py) with the first sample read as a header line
+    like every run of that folder -- the design EBENoutput_part1 was then fitted on at this table's optimum.  All 1200
+    fits (23 s): (alpha*, lambda*) = (0.5, 2.1954482538537206) exactly R's, cv.error at the optimum to 1e-16, 1156 fits
+    within 1e-9 of R; the other 44 -- all at alpha = 1, long add/delete trajectories, off by 9e-7 ... 2.3e-2 -- are
+    listed in tests/golden/looser13248_table_deviations.json with this build's values (same contract as
+    test_full_table_vs_real_r; regenerate with
+    `COLS=13248 SKIP_SINGLE=1 python tools/fulltest_probe.py out.json tests/golden/looser13248_table_deviations.json`)."""
+    import json, os
+    X, y, d = fulltest("looser19871")
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "looser13248_table_deviations.json")))
+    X = np.asfortranarray(X[:, :fx["columns"]])
+    fid = AssignToFolds(X, 3, sample_kind="Rounding")
+    alpha, lam = BuildGrid(X, y, 3)
+    key = {(round(float(a_), 6), "%.6e" % l_, int(f_)): m_
+           for f_, a_, l_, m_ in zip(d["detail_foldId"], d["detail_alpha"], d["detail_lambda"], d["detail_MSE"])}
+    want = np.array([[key[(round(float(a_), 6), "%.6e" % l_, f + 1)] for f in range(3)] for a_, l_ in zip(alpha, lam)])
+    with pareben_amd.Context(X, y, fid, 3) as ctx:
+        E, st, cnt = ctx.run(alpha, lam)
+    assert np.all(st & 9 == 0)                         # nothing stopped, nothing past the reference's basisMax = 754
+    rel = np.abs(E - want) / want
+    listed = np.zeros((400, 3), dtype=bool)
+    for p in fx["pairs"]:
+        listed[p["cell"], p["fold"] - 1] = True
+        assert alpha[p["cell"]] == 1.0
+        assert abs(E[p["cell"], p["fold"] - 1] - p["gpu"]) <= 1e-12 * abs(p["gpu"]), p     # the recorded value of this build
+    assert len(fx["pairs"]) <= 48                                       # 4 % of the table at most
+    assert rel[~listed].max() < 1e-9, np.argwhere((rel >= 1e-9) & ~listed)
+    assert rel.max() < 3e-2
+    a_s, l_s, se, cv, idx = summarise_cv(alpha, lam, E, 3)
+    assert a_s[idx] == float(d["alpha_optimal"]) and abs(l_s[idx] - float(d["lambda_optimal"])) <= 1e-15 * l_s[idx]
+    assert abs(cv[idx] - d["summary_MSE"][idx]) <= 1e-6 * d["summary_MSE"][idx]
+    order = np.lexsort((lam, alpha))
+    clean = ~listed.any(axis=1)[order]
+    d_mse = np.abs(cv - d["summary_MSE"]) / d["summary_MSE"]
+    d_se = np.abs(se - d["summary_SE"]) / d["summary_SE"]
+    assert np.allclose(a_s, d["summary_alpha"], rtol=0, atol=1e-15) and np.allclose(l_s, d["summary_lambda"], rtol=1e-13, atol=0)
+    assert d_mse[clean].max() < 1e-9 and d_se[clean].max() < 1e-6
+    assert d_mse.max() <= fx["max_rel_diff_summary_mse"] * 1.0001 + 1e-12 and d_se.max() <= fx["max_rel_diff_summary_se"] * 1.0001 + 1e-12
+
+
 def _same_fit(out, d, pre, N):
     """R's EBelasticNet.Gaussian list against ours: weight table (locus1, locus2, effect, posterior variance, t, p),
     WaldScore, Intercept, residVar."""
@@ -136,9 +179,9 @@ def test_looser19871_cell_vs_oracle(fulltest, monkeypatch):
     past the reference's basisMax = 503 in fold 3, which both sides flag and continue).  Fold 2 peaks above 1024 columns
     on this design; the fixture was computed with a 1024-column workspace, so PAREBEN_WS_CAP = 1024 here and the fit
     must come back stopped and reported (the default 2048-column workspace completes it:
-    test_active_sets_beyond_1024_columns).  (The real-R table stored for this
-    design, parEBENoutput_2018-08-15*.RDS, is not reproducible from the tree -- DESIGN.md section 7 -- so this case
-    is checked against the oracle only; its lambda grid is checked against the stored one.)"""
+    test_active_sets_beyond_1024_columns).  (No stored reference output exists for this design as a whole -- the real-R
+    table parEBENoutput_2018-08-15*.RDS belongs to its first 13 248 columns, test_second_table_vs_real_r -- so this
+    large-p case is checked against the oracle; its lambda grid, which is the same, against the stored one.)"""
     import json, os
     from pareben_amd.grid import AssignToFolds, BuildGrid
     X, y, d = fulltest("looser19871")

@@ -9,7 +9,8 @@ Stored outputs (R 3.5 + CRAN EBEN, read with tools/rdata.py -- a pure XDR parser
   EBENoutput_Zeo_2018-11-20*.RDS               same call on filter_matrix_main0.05_Zeo.zip[, 2:11397] + pheno_Zeo
   EBENoutput_epi0.08_2018-12-02*.RDS           same call on filter_matrix_main0.05_epi0.08.zip[, 2:11598] + pheno_Zeo
   parEBENoutput_2018-08-15*.RDS                CrossValidate(BASIS, y, nFolds = 3, Epis = "no", prior = "gaussian",
-        search = "global") on filter_matrix_looser_0.02_main_0.15_epi.zip[, 2:19872] + pheno1 (1200 fits)
+        search = "global") + pheno1 (1200 fits); inputs not named in the tree -- the first 13 248 columns of
+        filter_matrix_looser_0.02_main_0.15_epi.zip[, 2:19872] (tools/cv19871_prefix_probe.py); the fixture keeps the whole design
   EBENoutput_part1/2/3_2018-08-16*.RDS         EBelasticNet.Gaussian at that run's optimum; inputs not named in the tree --
         part1 / part2 are the first 13 248 / last 13 247 columns of the same design (tools/parts_probe.py), part3 unidentified
 
