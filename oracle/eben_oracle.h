@@ -12,6 +12,8 @@
  *     Second pin, whole fit outputs: the stored EBelasticNet.Gaussian results under paper_materials/Real Data
  *     Analysis/Full_Test (R 3.5 + CRAN EBEN, Nov/Dec 2018) -- feature list, effects, posterior variances, WaldScore,
  *     Intercept, residVar -- are reproduced to 2e-11 / 1e-14 (tests/test_oracle_golden.py::test_oracle_reproduces_real_r_refits).
+ *     And the optimum cell of the second stored CV table (parEBENoutput_2018-08-15*.RDS, K = 13 248) to 4e-16
+ *     (profiles/r02/oracle_vs_real_r_fits.json).
  *   Gf (eben_gm.c with the epistasis variant), Bm and Bf (eben_bm.c): PARITY UNPINNED.  The reference tree holds no
  *     output of an epistasis or a binomial fit, its C cannot be built in this image (it needs R's headers and
  *     BLAS/LAPACK), and the known answers in SURVEY.md section 10 came from a build behind stand-in headers, which
