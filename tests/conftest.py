@@ -64,11 +64,12 @@ def yeast():
 
 @pytest.fixture(scope="session")
 def fulltest():
-    """Inputs and stored real-R outputs of paper_materials/Real Data Analysis/Full_Test (tools/make_golden_fulltest.py).
+    """Inputs and stored real-R outputs of paper_materials/Real Data Analysis/Full_Test and Subset_Test ("subset5356":
+    read with col_names, all rows) (tools/make_golden_fulltest.py).
     fulltest(name) -> (X, y, fixture); the rows the authors' runs saw (their read.delim() took the first sample as a
     header line, Full_Test/dataprep.R:3-4), +-1 genotypes as doubles, column-major."""
     def load(name):
-        d = np.load(os.path.join(GOLDEN, "fulltest_%s.npz" % name))
+        d = np.load(os.path.join(GOLDEN, ("%s.npz" if name.startswith("subset") else "fulltest_%s.npz") % name))
         n, k = int(d["n"]), int(d["drop_first_row"])
         X = np.unpackbits(d["bits"], axis=0)[:n].astype(np.float64)[k:] * 2.0 - 1.0
         return np.asfortranarray(X), d["pheno"].astype(np.float64)[k:], d

@@ -1,6 +1,7 @@
 """Real-R parity on the Full_Test fixtures (tools/make_golden_fulltest.py), on the GPU through the package:
 the stored EBelasticNet.Gaussian fits and the stored 3-fold CrossValidate() table of parEBENoutput_2018-08-15*.RDS -- on the
-whole 19871-column design by default (a large-p case; not what R ran), on the columns R ran it on with COLS=13248.
+whole 19871-column design by default (a large-p case; not what R ran), on the columns R ran it on with COLS=13248;
+TABLE=subset5356 runs the Subset_Test table (tests/golden/subset5356.npz) instead.
 Writes a JSON report (argv[1], default gpurun_out/fulltest_probe.json)."""
 import json, os, sys, time
 import numpy as np
@@ -46,7 +47,7 @@ for name in (("zeo_main", "zeo_main_epi") if not os.environ.get("SKIP_SINGLE") e
     rep[name] = cmp_fit(out, d); rep[name]["wall_s"] = time.time() - t1; rep[name]["shape"] = list(X.shape)
 print(json.dumps(rep), flush=True)
 
-d = np.load(G + "/fulltest_looser19871.npz"); X, y = design(d)
+d = np.load(G + ("/subset5356.npz" if os.environ.get("TABLE") == "subset5356" else "/fulltest_looser19871.npz")); X, y = design(d)
 if os.environ.get("COLS"):                    # the stored table was computed on the first 13 248 columns (tools/cv19871_prefix_probe.py)
     X = np.asfortranarray(X[:, :int(os.environ["COLS"])])
 fid = AssignToFolds(X, 3, sample_kind="Rounding")

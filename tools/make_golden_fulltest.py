@@ -14,7 +14,15 @@ Stored outputs (R 3.5 + CRAN EBEN, read with tools/rdata.py -- a pure XDR parser
   EBENoutput_part1/2/3_2018-08-16*.RDS         EBelasticNet.Gaussian at that run's optimum; inputs not named in the tree --
         part1 / part2 are the first 13 248 / last 13 247 columns of the same design (tools/parts_probe.py), part3 unidentified
 
-Every one of these runs loaded its inputs the way Full_Test/dataprep.R:3-4 does -- read.delim() with its default
+  Subset_Test/SubsetParCV_5-2-2018.RDS (= Subset_4-15-2018_parCV.RDS) and Subset_4-15-2018_model.RDS
+        CrossValidate(nFolds = 3, "gaussian", "global") and the refit at its optimum on `filter_matrix` (5356 features) + pheno1
+        (Subset_Test/Subset_Test_Gaus_doMPI.R).  That file is one of the blobs missing from the tree (.MISSING_LARGE_BLOBS);
+        it is the 233 main-effect columns + 5123 pair columns of the authors' single-locus filter (SL_filter.R), and both
+        pieces are in the tree: filter_matrix_looser[, 2:234] and filter_matrix_looser_0.02_main_0.15_epi[, 14750:19872]
+        (tools/_subset probe of round 2: the stored cell and model come out to 1e-14).  Read with col_names, so all 3803 rows.
+        -> tests/golden/subset5356.npz
+
+Every run of Full_Test loaded its inputs the way Full_Test/dataprep.R:3-4 does -- read.delim() with its default
 header = TRUE on files that have no header line -- so the first sample of the design and of the phenotype became
 column names and the fits saw rows 2..n.  The fixtures keep all rows (``drop_first_row = 1`` records the
 convention); that this is what happened is not an assumption: lambda_max of the stored grid (3.158042295...) is
@@ -106,8 +114,33 @@ def main():
                    ("part3", "EBENoutput_part3_2018-08-16_11_03_50.RDS")):
         d.update(fit_fields(f, tag + "_"))
     np.savez_compressed(OUT + "/fulltest_looser19871.npz", **d)
+    # 4. Subset_Test: the missing 5356-column `filter_matrix`, put together from its two pieces
+    big = d["bits"]; nb = int(d["n"])
+    epi = (np.unpackbits(big, axis=0)[:nb][:, 14748:] > 0)
+    main = []
+    with zipfile.ZipFile(FT + "filter_matrix_looser.zip").open("filter_matrix_looser") as f:
+        for line in io.TextIOWrapper(f, newline=None):
+            main.append(np.array(line.split("\t", 234)[1:234], dtype=np.int8))
+    main = np.stack(main) > 0
+    assert main.shape == (3803, 233) and epi.shape == (3803, 5123)
+    ST = "/root/reference/paper_materials/Real Data Analysis/Subset_Test/"
+    s = dict(bits=np.packbits(np.hstack([main, epi]).astype(np.uint8), axis=0), n=np.int64(3803), p=np.int64(5356), drop_first_row=np.int64(0),
+             pheno=np.loadtxt(ST + "pheno1"))
+    g = simplify(read_rds(ST + "SubsetParCV_5-2-2018.RDS"))
+    g2 = simplify(read_rds(ST + "Subset_4-15-2018_parCV.RDS"))
+    assert np.array_equal(np.asarray(g["Results.Detail"]["MSE"]), np.asarray(g2["Results.Detail"]["MSE"]))      # the same table twice
+    D, S = g["Results.Detail"], g["Results.Summary"]
+    s.update(detail_foldId=np.asarray(D["foldId"]), detail_alpha=np.asarray(D["alpha"]), detail_lambda=np.asarray(D["lambda"]),
+             detail_MSE=np.asarray(D["MSE"]), summary_alpha=np.asarray(S["alpha"]), summary_lambda=np.asarray(S["lambda"]),
+             summary_SE=np.asarray(S["SE"]), summary_MSE=np.asarray(S["MSE"]),
+             lambda_optimal=np.float64(np.asarray(g["lambda.optimal"]).reshape(-1)[0]),
+             alpha_optimal=np.float64(np.asarray(g["alpha.optimal"]).reshape(-1)[0]))
+    o = simplify(read_rds(ST + "Subset_4-15-2018_model.RDS"))
+    for k_ in ("weight", "WaldScore", "Intercept", "residVar", "lambda", "alpha"):
+        s["model_" + k_] = np.asarray(o[k_], dtype=np.float64) if k_ == "weight" else np.float64(np.asarray(o[k_]).reshape(-1)[0])
+    np.savez_compressed(OUT + "/subset5356.npz", **s)
     for f in sorted(os.listdir(OUT)):
-        if f.startswith("fulltest_"):
+        if f.startswith("fulltest_") or f.startswith("subset"):
             print(f, os.path.getsize(OUT + "/" + f))
 
 
