@@ -86,6 +86,31 @@ def test_summary_matches_real_r_tables(golden):
     assert l_s[idx] == r["lambda_optimal"][0] and a_s[idx] == r["alpha_optimal"][0]
 
 
+def test_grid_folds_summary_on_the_other_real_r_tables(fulltest):
+    """The same R-level pieces on the two other stored real-R tables (August 2018: first 13 248 columns of the 19 871-column
+    design, rows 2..n; April/May 2018: the reassembled 5356-column Subset_Test design, all rows): BuildGrid's alpha /
+    lambda values, and Results.Detail -> Results.Summary -> (lambda.optimal, alpha.optimal).  Both runs stored their
+    Detail rows in another order than the May 2018 one (fold fastest within (alpha, lambda) blocks that are not sorted):
+    the summary does not depend on it."""
+    for name, cols in (("looser19871", 13248), ("subset5356", None)):
+        X, y, d = fulltest(name)
+        if cols:
+            X = X[:, :cols]
+        alpha, lam = BuildGrid(X, y, 3)
+        assert np.allclose(np.unique(alpha), np.unique(d["detail_alpha"]), rtol=0, atol=1e-15)
+        assert np.allclose(np.unique(lam), np.unique(d["detail_lambda"]), rtol=1e-13, atol=0)
+        key = {(round(float(a_), 6), "%.6e" % l_, int(f_)): m_
+               for f_, a_, l_, m_ in zip(d["detail_foldId"], d["detail_alpha"], d["detail_lambda"], d["detail_MSE"])}
+        assert len(key) == 1200
+        E = np.array([[key[(round(float(a_), 6), "%.6e" % l_, f + 1)] for f in range(3)] for a_, l_ in zip(alpha, lam)])
+        a_s, l_s, se, err, idx = summarise_cv(alpha, lam, E, 3)
+        assert np.allclose(a_s, d["summary_alpha"], rtol=0, atol=1e-15) and np.allclose(l_s, d["summary_lambda"], rtol=1e-13, atol=0)
+        assert np.allclose(err, d["summary_MSE"], rtol=1e-14, atol=0) and np.allclose(se, d["summary_SE"], rtol=1e-11, atol=0)
+        assert abs(l_s[idx] - float(d["lambda_optimal"])) <= 1e-14 * l_s[idx] and abs(a_s[idx] - float(d["alpha_optimal"])) < 1e-15
+        fid = AssignToFolds(X, 3, sample_kind="Rounding")
+        assert sorted(np.bincount(fid)[1:].tolist()) == sorted([X.shape[0] // 3 + (1 if k < X.shape[0] % 3 else 0) for k in range(3)])
+
+
 def test_summary_binomial_intent():
     alpha = np.array([1.0, 0.5]); lam = np.array([0.3, 0.3])
     E = np.array([[-0.6, -0.7], [-0.4, -0.5]])
