@@ -19,7 +19,8 @@ Stored outputs (R 3.5 + CRAN EBEN, read with tools/rdata.py -- a pure XDR parser
         (Subset_Test/Subset_Test_Gaus_doMPI.R).  That file is one of the blobs missing from the tree (.MISSING_LARGE_BLOBS);
         it is the 233 main-effect columns + 5123 pair columns of the authors' single-locus filter (SL_filter.R), and both
         pieces are in the tree: filter_matrix_looser[, 2:234] and filter_matrix_looser_0.02_main_0.15_epi[, 14750:19872]
-        (tools/_subset probe of round 2: the stored cell and model come out to 1e-14).  Read with col_names, so all 3803 rows.
+        (checked by what comes out: the stored table's first cell and the stored refit to 1e-14,
+        tests/test_real_r_golden_gpu.py::test_third_table_vs_real_r).  Read with col_names, so all 3803 rows.
         -> tests/golden/subset5356.npz
 
 Every run of Full_Test loaded its inputs the way Full_Test/dataprep.R:3-4 does -- read.delim() with its default
