@@ -1,5 +1,5 @@
 """Which inputs produced Full_Test/EBENoutput_part1..3 (2018-08-16; lambda = 2.195448, alpha = 0.5 -- the optimum of the
-previous day's CrossValidate() run on the 19 871-column design)?  The files name none.  On the GPU, fits over column
+previous day's CrossValidate() run, itself on the first 13 248 columns of the 19 871-column design)?  The files name none.  On the GPU, fits over column
 windows, column thirds (in every order) and row conventions of that design, printed next to the stored feature count /
 Wald score / residual variance / intercept / largest locus.
 
