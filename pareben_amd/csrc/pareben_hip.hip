@@ -1028,8 +1028,8 @@ static int run_enqueue(pareben_ctx *c, int n_cells, const double *alpha, const d
     // features enter (a third of the grid costs nothing), the heaviest fits -- seconds each, against a mean of
     // 0.2 s -- sit right below it at the sparse-to-dense transition (its position moves with alpha), and from there
     // down the cost is flat.  So the queue simply runs from the large-lambda end: the free cells fly by, the heavy
-    // ridge starts within the first milliseconds, and the uniform plateau packs the tail.  (Until the end of round 2
-    // one cell in four was taken from the small-lambda end instead; measured on rank shares of config 2 the plain
+    // ridge starts within the first milliseconds, and the uniform plateau packs the tail.  (Earlier builds took
+    // one cell in four from the small-lambda end instead; measured on rank shares of config 2 the plain
     // descending order is as fast on a full grid -- 7.98 vs 7.99 s -- and better when a launch holds few fits per
     // workgroup, where a late heavy fit is the critical path: 4.40 -> 4.20 s for a half grid, 2.88 -> 2.67 s for a
     // quarter.  PAREBEN_QUEUE_MIX=<n> brings the interleave back for A/B runs.)
