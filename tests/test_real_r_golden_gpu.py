@@ -107,9 +107,16 @@ def test_second_table_vs_real_r(fulltest):
     key = {(round(float(a_), 6), "%.6e" % l_, int(f_)): m_
            for f_, a_, l_, m_ in zip(d["detail_foldId"], d["detail_alpha"], d["detail_lambda"], d["detail_MSE"])}
     want = np.array([[key[(round(float(a_), 6), "%.6e" % l_, f + 1)] for f in range(3)] for a_, l_ in zip(alpha, lam)])
-    with pareben_amd.Context(X, y, fid, 3) as ctx:
-        E, st, cnt = ctx.run(alpha, lam)
+    # through the drop-in entry: the object CrossValidate() returns is what is compared with R's
+    out = pareben_amd.CrossValidate(X, y, 3, sample_kind="Rounding", return_stats=True)
+    D = out["Results.Detail"]
+    assert np.array_equal(np.asarray(D["alpha"])[::3], alpha) and np.array_equal(np.asarray(D["lambda"])[::3], lam)
+    assert np.array_equal(np.asarray(D["foldId"])[:3], [1, 2, 3])
+    E = np.asarray(D["MSE"]).reshape(400, 3); st = out["stats"]["status"]
     assert np.all(st & 9 == 0)                         # nothing stopped, nothing past the reference's basisMax = 754
+    assert out["alpha.optimal"] == float(d["alpha_optimal"]) and abs(out["lambda.optimal"] - float(d["lambda_optimal"])) <= 1e-15 * out["lambda.optimal"]
+    S = out["Results.Summary"]
+    assert np.allclose(np.asarray(S["alpha"]), d["summary_alpha"], rtol=0, atol=1e-15) and np.allclose(np.asarray(S["lambda"]), d["summary_lambda"], rtol=1e-13, atol=0)
     rel = np.abs(E - want) / want
     listed = np.zeros((400, 3), dtype=bool)
     for p in fx["pairs"]:
