@@ -192,6 +192,37 @@ int pareben_fit_binomial_epis(const double *basis, const double *target, double 
                               double *logLikelihood, double *Beta, double *wald, double *intercept,
                               int n, int k, int verbose, int bMax, int device, int64_t *counters);
 
+/*
+ * The reference's own .C entry points: the symbol names, argument order and pointer-only convention of EBEN_orig/src,
+ * so R's .C() binds them with nothing but PACKAGE changed:
+ *   elasticNetLinearNeMainEff   EBEN_orig/src/elasticNetLinearNeMainEff.c:55-57   <- EBEN_orig/R/EBelasticNet.Gaussian.R:38-51
+ *   elasticNetLinearNeEpisEff   EBEN_orig/src/elasticNetLinearNeFull2.c:57-58     <- EBEN_orig/R/EBelasticNet.Gaussian.R:16-29
+ *   ElasticNetBinaryNEmainEff   EBEN_orig/src/ElasticNetBinaryNEmainEff.c:236-238 <- EBEN_orig/R/EBelasticNet.Binomial.R:32-46
+ *   ElasticNetBinaryNEfull      EBEN_orig/src/ElasticNetBinaryNeFull.c:52-55      <- EBEN_orig/R/EBelasticNet.Binomial.R:10-24
+ * Each forwards to the pareben_fit_* entry above on device PAREBEN_DEVICE (default 0) and writes its outputs in place.
+ * `verb` is honoured (stdout): > 0 basisMax, > 1 start / finish lines, > 2 one line per outer iteration
+ * (elasticNetLinearNeMainEff.c:70-71, :196, :205; ElasticNetBinaryNEmainEff.c:327, :342, :352), > 4 one line per inner
+ * iteration (:405, Gaussian).  .C has no error channel: on failure the message goes to stderr and the scalar outputs are NaN.
+ */
+void elasticNetLinearNeMainEff(double *BASIS, double *y, double *a_lambda, double *b_Alpha, double *Beta,
+                               double *wald, double *intercept, int *n, int *kdim, int *verb, double *residual);
+void elasticNetLinearNeEpisEff(double *BASIS, double *y, double *a_lambda, double *b_Alpha, double *Beta,
+                               double *wald, double *intercept, int *n, int *kdim, int *VB, double *residual);
+void ElasticNetBinaryNEmainEff(double *BASIS, double *Targets, double *a_Lambda, double *b_Alpha, double *logLIKELIHOOD,
+                               double *Beta, double *wald, double *intercept, int *n, int *kdim, int *VB, int *bMax);
+void ElasticNetBinaryNEfull(double *BASIS, double *Targets, double *a_Lambda, double *b_Alpha, double *logLIKELIHOOD,
+                            double *Beta, double *wald, double *intercept, int *n, int *kdim, int *VB, int *bMax);
+
+/*
+ * Diagnostics: decision trace of the following pareben_fit_gaussian[_epis] calls of the calling thread.  One record of
+ * 16 64-bit words per inner iteration of elasticNetLinearNeMainEff.c:401-731 (the arg-max feature, its action and dML,
+ * the runner-up, the block cut-off and the nearest dML to it, the noise precision and order-free XOR hashes of S_in,
+ * Q_in, (Sigma, mu) afterwards; layout TR_* in pareben_amd/csrc/types.h).  buf[0] = records written, records start at
+ * buf + 16; at most max_records are kept.  NULL switches it off.  oracle/eben_gm.c writes the same layout
+ * (eben_set_trace), which is how tools/trace_divergence.py finds the first decision on which two builds part.
+ */
+int pareben_set_trace(uint64_t *buf, int64_t max_records);
+
 #ifdef __cplusplus
 }
 #endif

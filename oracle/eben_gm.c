@@ -26,6 +26,19 @@
 #define TRACE(...)
 #endif
 
+/* ---- decision trace (diagnostics; tools/trace_divergence.py).  One 16-slot record of 64-bit words per inner
+ * iteration, the same layout the HIP build writes (pareben_amd/csrc/types.h, TR_*): what was decided, by what
+ * margin, and order-free XOR hashes of the state afterwards, so that two builds can be compared record by record
+ * and the first differing decision be read off together with the distance of the runner-up.  buf[0] = records
+ * written; records start at buf + 16. */
+enum { TR_ITER, TR_IITER, TR_MBEFORE, TR_NU, TR_ACT, TR_NTODO, TR_SEL, TR_MAFTER,
+       TR_BEST, TR_SECOND, TR_CUTOFF, TR_NEAREST, TR_BETA, TR_HSIN, TR_HQIN, TR_HSIG, TR_NSLOT };
+static uint64_t *g_trace = NULL;
+static int64_t g_trace_cap = 0;
+void eben_set_trace(uint64_t *buf, int64_t max_records) { g_trace = buf; g_trace_cap = max_records; if (buf) buf[0] = 0; }
+static uint64_t dbits(double v) { uint64_t u; memcpy(&u, &v, 8); return u; }
+static uint64_t *trace_rec(void) { return (g_trace && (int64_t)g_trace[0] < g_trace_cap) ? g_trace + TR_NSLOT * (g_trace[0] + 1) : NULL; }
+
 enum { ACT_NONE = -10, ACT_REEST = 0, ACT_ADD = 1, ACT_DEL = -1, ACT_TERM = 10 };
 
 typedef struct {
@@ -40,6 +53,7 @@ typedef struct {
 typedef struct {
     gm_variant v;
     int N, K, cap;
+    int n_main;                /* columns 0..n_main-1 are main effects (PHI = x * (1/scale)); pair columns behind them are divided (Full2.c:544) */
     int cap_ref;               /* the reference's basisMax (<= cap); see eben_set_capacity_policy */
     const double *X, *y;
     double lambda, alpha;
@@ -417,6 +431,23 @@ static int gm_inner(gm *s, int iter, double residual, double varY, double *cs, d
             if (n_todo == 0) worthwhile = 0;
         }
         if (!worthwhile) sel = ACT_TERM;
+        uint64_t *tr = trace_rec();
+        if (tr) {
+            double cutoff = 0, second = 0, nearest = INFINITY;
+            if (worthwhile && nu >= 0) {
+                cutoff = best * (s->act[nu] == ACT_ADD ? s->v.n_add : 1.0);
+                if (cutoff < s->v.ml_delta) cutoff = s->v.ml_delta;
+            }
+            for (int i = 0; i < K; i++) {
+                const double d = s->dml[i];
+                if (!(d > 0)) continue;
+                if (i != nu && d > second) second = d;
+                if (cutoff > 0 && fabs(d - cutoff) / cutoff < nearest) nearest = fabs(d - cutoff) / cutoff;
+            }
+            tr[TR_ITER] = iter; tr[TR_IITER] = i_iter; tr[TR_MBEFORE] = s->M; tr[TR_NU] = (uint64_t)(int64_t)nu;
+            tr[TR_ACT] = (uint64_t)(int64_t)(nu >= 0 ? s->act[nu] : ACT_NONE); tr[TR_NTODO] = worthwhile ? n_todo : 0;
+            tr[TR_BEST] = dbits(best); tr[TR_SECOND] = dbits(second); tr[TR_CUTOFF] = dbits(cutoff); tr[TR_NEAREST] = dbits(nearest);
+        }
         if (worthwhile) {
             for (int u = 0; u < n_todo; u++) {
                 nu = s->todo[u];
@@ -430,8 +461,11 @@ static int gm_inner(gm *s, int iter, double residual, double varY, double *cs, d
                         if (jj < 0 || jj >= s->M) { free(phi); free(e); return 1; }
                     }
                 }
-                double r = 1 / s->scale[nu];
-                for (int h = 0; h < N; h++) phi[h] = s->X[(size_t)nu * N + h] * r;
+                if (nu < s->n_main) {          /* dcopy + dscal with 1/Scales, :517-520 (Full2.c:530-535) */
+                    double r = 1 / s->scale[nu];
+                    for (int h = 0; h < N; h++) phi[h] = s->X[(size_t)nu * N + h] * r;
+                } else                          /* pair column: x_i x_j / Scales, Full2.c:544 */
+                    for (int h = 0; h < N; h++) phi[h] = s->X[(size_t)nu * N + h] / s->scale[nu];
                 if (sel == ACT_REEST && fabs(log(newA) - log(s->A[jj])) <= s->v.reest_tol && any_del == 0)
                     sel = ACT_TERM;
                 int upd = 0;
@@ -480,6 +514,14 @@ static int gm_inner(gm *s, int iter, double residual, double varY, double *cs, d
             }
         }
         TRACE("  it %d.%d M=%d sel=%d ntodo=%d beta=%.15g mu0=%.15g A0=%.15g gam0=%.15g\n", iter, i_iter, s->M, sel, n_todo, s->beta, s->mu[0], s->A[0], s->gam[0]);
+        if (tr) {
+            uint64_t hs = 0, hq = 0, hg = 0;
+            for (int i = 0; i < K; i++) { hs ^= dbits(s->Sin[i]); hq ^= dbits(s->Qin[i]); }
+            for (int j = 0; j < s->M; j++) { hg ^= dbits(s->mu[j]); for (int i = 0; i < s->M; i++) hg ^= dbits(s->Sig[(size_t)j * s->M + i]); }
+            tr[TR_SEL] = (uint64_t)(int64_t)sel; tr[TR_MAFTER] = s->M; tr[TR_BETA] = dbits(s->beta);
+            tr[TR_HSIN] = hs; tr[TR_HQIN] = hq; tr[TR_HSIG] = hg;
+            g_trace[0]++;
+        }
         if (sel == ACT_TERM && ini_removed) last_it = 1;
         if ((i_iter == it_max && s->M == 1) || i_iter > it_max) last_it = 1;
         if (i_iter == it_max) sel = ACT_TERM;
@@ -535,7 +577,7 @@ static void capacities(int ref_rule, long K, int N, int *cap_ref, int *cap)
     *cap_ref = (int)ref; *cap = (int)c;
 }
 
-static int gm_core(const gm_variant *v, const double *X, const double *y, int N, int K, int cap, int cap_ref, const double *scale_in,
+static int gm_core(const gm_variant *v, const double *X, const double *y, int N, int K, int n_main, int cap, int cap_ref, const double *scale_in,
                    double lambda, double alpha, int *M_out, int *used_out, double *w_out, double *var_out,
                    double *wald, double *intercept, double *residual, eben_counters *cnt)
 {
@@ -544,6 +586,7 @@ static int gm_core(const gm_variant *v, const double *X, const double *y, int N,
     s->v = *v;
     s->N = N; s->K = K; s->X = X; s->y = y; s->lambda = lambda; s->alpha = alpha;
     s->cap = cap;
+    s->n_main = n_main;
     s->cap_ref = cap_ref;
     s->scale = (double *)calloc(K, sizeof(double));
     memcpy(s->scale, scale_in, sizeof(double) * K);
@@ -629,7 +672,7 @@ int eben_gm_fit(const double *X, const double *y, int N, int K, double lambda, d
     int M = 0;
     int *used = (int *)calloc(cap + 1, sizeof(int));
     double *w = (double *)calloc(cap + 1, sizeof(double)), *vr = (double *)calloc(cap + 1, sizeof(double));
-    int rc = gm_core(&v, X, y, N, K, cap, cap_ref, scale, lambda, alpha, &M, used, w, vr, wald, intercept, residual, cnt);
+    int rc = gm_core(&v, X, y, N, K, K, cap, cap_ref, scale, lambda, alpha, &M, used, w, vr, wald, intercept, residual, cnt);
     for (int i = 0; i < M; i++) { Beta[2 * (size_t)K + used[i]] = w[i]; Beta[3 * (size_t)K + used[i]] = vr[i]; }
     free(scale); free(used); free(w); free(vr);
     return rc;
@@ -671,7 +714,7 @@ int eben_gf_fit(const double *X, const double *y, int N, int K, double lambda, d
     int M = 0;
     int *used = (int *)calloc(cap + 1, sizeof(int));
     double *w = (double *)calloc(cap + 1, sizeof(double)), *vr = (double *)calloc(cap + 1, sizeof(double));
-    int rc = gm_core(&v, Z, y, N, (int)MF, cap, cap_ref, scale, lambda, alpha, &M, used, w, vr, wald, intercept, residual, cnt);
+    int rc = gm_core(&v, Z, y, N, (int)MF, K, cap, cap_ref, scale, lambda, alpha, &M, used, w, vr, wald, intercept, residual, cnt);
     for (int i = 0; i < M; i++) {
         Beta[2 * MF + used[i]] = w[i]; Beta[3 * MF + used[i]] = vr[i]; Beta[4 * MF + used[i]] = used[i] + 1;   /* :232-238 */
     }

@@ -48,6 +48,10 @@ typedef struct {
  * basisMax lowered to r when r > 0.  Process-wide; set before fitting. */
 void eben_set_capacity_policy(int continue_past_basismax, int ref_cap_override);
 
+/* Decision trace of the next Gaussian fit(s) (diagnostics, single-threaded use): 16 64-bit words per inner iteration
+ * (layout: eben_gm.c, TR_*), buf[0] = records written, records from buf + 16; NULL switches it off. */
+void eben_set_trace(uint64_t *buf, int64_t max_records);
+
 /* Gaussian, main effects.  Follows EBEN_orig/src/elasticNetLinearNeMainEff.c:55-242.
  * X is N x K column-major, Beta is K x 4 column-major (loc1, loc2, beta, var). */
 int eben_gm_fit(const double *X, const double *y, int N, int K, double lambda, double alpha,

@@ -200,3 +200,37 @@ def fit_binomial(BASIS, Target, lam, alpha, device=0, epis=False):
             n, k, 0, 2 * k if epis else k, int(device), _lp(cnt)), name)
     return dict(Beta=Beta, logLikelihood=ll.value, wald=wald.value, intercept=icpt,
                 counters=dict(zip(COUNTER_NAMES, (int(v) for v in cnt))))
+
+
+def dot_c(name, BASIS, Target, lam, alpha, verbose=0):
+    """R's .C(name, BASIS, Target, lamda, alpha, ..., PACKAGE = "pareben_hip") spelled in ctypes: the reference's own
+    symbol (elasticNetLinearNeMainEff | elasticNetLinearNeEpisEff | ElasticNetBinaryNEmainEff | ElasticNetBinaryNEfull),
+    every argument a pointer, outputs written in place, no return value -- the tuples of
+    EBEN_orig/R/EBelasticNet.Gaussian.R:16-51 and EBEN_orig/R/EBelasticNet.Binomial.R:10-46 -> the same dicts as
+    fit_gaussian / fit_binomial (without counters)."""
+    L = load()
+    X = np.asfortranarray(BASIS, dtype=np.float64)
+    y = np.ascontiguousarray(Target, dtype=np.float64).reshape(-1)
+    n, k = X.shape
+    N, K, VB = C.c_int(n), C.c_int(k), C.c_int(int(verbose))
+    lam_, alpha_ = C.c_double(float(lam)), C.c_double(float(alpha))
+    fn = getattr(L, name)
+    fn.restype = None
+    wald = C.c_double(0)
+    if name in ("elasticNetLinearNeMainEff", "elasticNetLinearNeEpisEff"):
+        epis = name.endswith("EpisEff")
+        Beta = np.zeros((k * (k + 1) // 2, 5), order="F") if epis else np.zeros((k, 4), order="F")
+        icpt, resid = C.c_double(0), C.c_double(0)
+        fn(_dp(X), _dp(y), C.byref(lam_), C.byref(alpha_), _dp(Beta), C.byref(wald), C.byref(icpt), C.byref(N), C.byref(K),
+           C.byref(VB), C.byref(resid))
+        return dict(Beta=Beta, wald=wald.value, intercept=icpt.value, residual=resid.value)
+    if name in ("ElasticNetBinaryNEmainEff", "ElasticNetBinaryNEfull"):
+        epis = name.endswith("full")
+        bmax = C.c_int(2 * k if epis else k)
+        Beta = np.zeros((bmax.value, 4), order="F")
+        ll = C.c_double(0)
+        icpt = np.zeros(2)
+        fn(_dp(X), _dp(y), C.byref(lam_), C.byref(alpha_), C.byref(ll), _dp(Beta), C.byref(wald), _dp(icpt), C.byref(N), C.byref(K),
+           C.byref(VB), C.byref(bmax))
+        return dict(Beta=Beta, logLikelihood=ll.value, wald=wald.value, intercept=icpt)
+    raise ValueError(name)

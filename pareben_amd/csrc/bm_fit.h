@@ -998,6 +998,7 @@ DEV void bm_fit(const Blk &B, const FoldDev &F, const BmWork &W, int K, double l
         else { PAR(i, S.M) ap += fabs(W.A[i]); }               // NEmainEff.c:340: dasum over M = N_used + 1 entries (Q12)
         vk = blk_sum(B, ap);
         err = fabs(vk - vk0) / S.M;
+        if (S.outer_log && B.tid == 0) { double *o = S.outer_log + 3 * (iter - 1); o[0] = err; o[1] = 0; o[2] = 0; }   // NEmainEff.c:342
     }
     *loglik = ll;
     CNT(c.n_outer = iter; c.m_final = S.M - 1; c.status = S.status);

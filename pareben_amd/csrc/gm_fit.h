@@ -65,6 +65,9 @@ struct GmScalars {
     int fold = 0;
     int bp_ok = 0;     // binomial: model columns for which the weighted rows BP are current (0 = stale)
     int gc_ok = 0;     // Gaussian, device: the Gram block cache W.Gc matches the active set's slots (0 = rebuild at the next Hessian)
+    unsigned long long *trace = nullptr;   // decision trace (types.h TR_*; null = off), trace_cap records
+    long long trace_cap = 0;
+    double *outer_log = nullptr;           // per-fit entries with verbose > 2: (err, intercept | -, residual variance | -) per outer iteration
 };
 #define CNT(stmt) do { if (B.tid == 0) { FitCounters &c = *S.c; stmt; } } while (0)
 
@@ -966,17 +969,18 @@ DEVNI int gm_row(const Blk &B, const FoldDev &F, const GmWork &W, int K, int u)
     const int N = F.N;
     double *row = const_cast<double *>(F.G) + (size_t)my * K;
     const double *xu = F.X + (size_t)u * N;
-    const double su = F.scale[u];                               // PHI = x_u / |x_u| as the reference forms it (:1608-1617)
+    // PHI as the reference forms it: a main-effect column times the reciprocal of its norm (:517-520), a pair column divided by it (Full2.c:544)
+    const double su = u < F.n_main ? 1.0 : F.scale[u], ru = u < F.n_main ? F.rscale[u] : 1.0;
     const bool in_lds = N <= B.pool_n;
     if (in_lds) {
-        PAR(h, N) B.pool[h] = xu[h] / su;
+        PAR(h, N) B.pool[h] = xu[h] * ru / su;                  // one of the two factors is exactly 1
         blk_sync(B);
     }
 #ifdef PAREBEN_HOST_EMUL
     for (int i = B.wave; i < K; i += B.nwave) {
         const double *xi = F.X + (size_t)i * N;
         double a = 0;
-        for (int h = B.lane; h < N; h += BLK_LANES) a += xi[h] * (xu[h] / su);
+        for (int h = B.lane; h < N; h += BLK_LANES) a += xi[h] * (xu[h] * ru / su);
         if (B.lane == 0) row[i] = a / F.scale[i];
     }
 #else
@@ -988,7 +992,7 @@ DEVNI int gm_row(const Blk &B, const FoldDev &F, const GmWork &W, int K, int u)
             const double *xi = F.X + (size_t)(i0 + c < K ? i0 + c : K - 1) * N;
             double t = 0;
             if (in_lds) for (int h = B.lane; h < N; h += BLK_LANES) t += xi[h] * B.pool[h];
-            else for (int h = B.lane; h < N; h += BLK_LANES) t += xi[h] * (xu[h] / su);
+            else for (int h = B.lane; h < N; h += BLK_LANES) t += xi[h] * (xu[h] * ru / su);
             a[c] = t;
         }
         wave_sum8(a, B.lane);
@@ -1172,8 +1176,9 @@ DEVNI void gm_rows_prefetch(const Blk &B, const FoldDev &F, int K, const int *nu
     if (C == 0) return;
     for (int c = 0; c < C; c++) {
         const double *xu = F.X + (size_t)lfeat[c] * N;
-        const double su = F.scale[lfeat[c]];
-        PAR(h, N) B.pool[c * N + h] = xu[h] / su;
+        const bool mainc = lfeat[c] < F.n_main;
+        const double su = mainc ? 1.0 : F.scale[lfeat[c]], ru = mainc ? F.rscale[lfeat[c]] : 1.0;
+        PAR(h, N) B.pool[c * N + h] = xu[h] * ru / su;
     }
     blk_sync(B);
     double *Gw = const_cast<double *>(F.G);
@@ -1795,6 +1800,81 @@ DEV void gm_model_at2(const Blk &B, const FoldDev &F, int M, int N, int h0, int 
 }
 #endif
 
+// ---- decision trace (diagnostics only: S.trace is null in every production launch) -------------------------
+DEV unsigned long long gm_dbits(double v) { unsigned long long u; __builtin_memcpy(&u, &v, 8); return u; }
+DEV unsigned long long blk_xor64(const Blk &B, unsigned long long v)
+{
+#ifndef PAREBEN_HOST_EMUL
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v ^= __shfl_xor(v, o, 64);
+    unsigned long long *r = (unsigned long long *)B.red;
+    __syncthreads();
+    if (B.lane == 0) r[B.wave] = v;
+    __syncthreads();
+    v = 0;
+    for (int w = 0; w < B.nwave; w++) v ^= r[w];
+    __syncthreads();
+#else
+    (void)B;
+#endif
+    return v;
+}
+DEV double blk_max(const Blk &B, double v)
+{
+    double bv; int bi;
+    blk_argmax(B, v, 0, &bv, &bi);
+    blk_sync(B);
+    return bv;
+}
+// the record of this inner iteration, or null (thread-uniform)
+DEV unsigned long long *gm_trace_rec(const GmScalars &S)
+{
+    return (S.trace && (long long)S.trace[0] < S.trace_cap) ? S.trace + TR_NSLOT * (S.trace[0] + 1) : nullptr;
+}
+// the decision: arg-max feature, its action and value, the runner-up, the block cut-off and the relative distance of
+// the nearest dML to it (what a last-bit change would have to bridge to alter the to-do list)
+DEVNI void gm_trace_decision(const Blk &B, const GmWork &W, int K, const GmScalars &S, unsigned long long *tr, int iter, int i_iter,
+                             int nu, double best, int worthwhile, int n_todo)
+{
+    double cutoff = 0;
+    if (worthwhile && nu >= 0) {
+        cutoff = best * (W.act[nu] == ACT_ADD ? S.v.n_add : 1.0);
+        if (cutoff < S.v.ml_delta) cutoff = S.v.ml_delta;
+    }
+    double second = 0, nearest = -INFINITY;                    // nearest: max of the negated distance
+    PAR(i, K) {
+        const double d = W.dml[i];
+        if (!(d > 0)) continue;
+        if (i != nu && d > second) second = d;
+        if (cutoff > 0 && -(fabs(d - cutoff) / cutoff) > nearest) nearest = -(fabs(d - cutoff) / cutoff);
+    }
+    second = blk_max(B, second);
+    nearest = blk_max(B, nearest);
+    if (B.tid == 0) {
+        tr[TR_ITER] = iter; tr[TR_IITER] = i_iter; tr[TR_MBEFORE] = S.M; tr[TR_NU] = (unsigned long long)(long long)nu;
+        tr[TR_ACT] = (unsigned long long)(long long)(nu >= 0 ? W.act[nu] : ACT_NONE); tr[TR_NTODO] = worthwhile ? n_todo : 0;
+        tr[TR_BEST] = gm_dbits(best); tr[TR_SECOND] = gm_dbits(second); tr[TR_CUTOFF] = gm_dbits(cutoff); tr[TR_NEAREST] = gm_dbits(-nearest);
+    }
+    blk_sync(B);
+}
+// the state after the iteration: XOR of the bit patterns of S_in, Q_in and (Sigma, mu) -- order-free, so equal
+// hashes on two builds mean equal bits whatever the layout
+DEVNI void gm_trace_state(const Blk &B, const GmWork &W, int K, const GmScalars &S, unsigned long long *tr, int sel)
+{
+    unsigned long long hs = 0, hq = 0, hg = 0;
+    PAR(i, K) { hs ^= gm_dbits(W.Sin[i]); hq ^= gm_dbits(W.Qin[i]); }
+    const int M = S.M;
+    for (int e = B.tid; e < M * M; e += B.nthr) { const int j = e / M, i = e - j * M; hg ^= gm_dbits(W.Sig[(size_t)j * W.ld + i]); }
+    PAR(j, M) hg ^= gm_dbits(W.mu[j]);
+    hs = blk_xor64(B, hs); hq = blk_xor64(B, hq); hg = blk_xor64(B, hg);
+    if (B.tid == 0) {
+        tr[TR_SEL] = (unsigned long long)(long long)sel; tr[TR_MAFTER] = M; tr[TR_BETA] = gm_dbits(S.beta);
+        tr[TR_HSIN] = hs; tr[TR_HQIN] = hq; tr[TR_HSIG] = hg;
+        S.trace[0]++;
+    }
+    blk_sync(B);
+}
+
 // One call of the inner routine (MainEff.c:248-809) for outer iteration `iter`.  On return
 // *cs = sum_i Csum_i and *csy = Csum.y with Csum the column sums of
 // C^-1 = beta I - beta^2 Phi Sigma Phi' (:741-781, :172-187), formed in O(N M + M^2).
@@ -1872,6 +1952,8 @@ DEV int gm_inner(const Blk &B, const FoldDev &F, const GmWork &W, int K, double 
         }
         if (!worthwhile) sel = ACT_TERM;
         PH_END(PH_DML);
+        unsigned long long *const tr = gm_trace_rec(S);
+        if (tr) gm_trace_decision(B, W, K, S, tr, iter, i_iter, nu, best, worthwhile, n_todo);
         if (worthwhile) {
             PH_BEGIN();
             for (int u = 0; u < n_todo; u++) {
@@ -1992,6 +2074,7 @@ DEV int gm_inner(const Blk &B, const FoldDev &F, const GmWork &W, int K, double 
             }
         }
         GM_TRACE("  it %d.%d M=%d sel=%d ntodo=%d beta=%.15g mu0=%.15g A0=%.15g gam0=%.15g\n", iter, i_iter, S.M, sel, n_todo, S.beta, W.mu[0], W.A[0], W.gam[0]);
+        if (tr) gm_trace_state(B, W, K, S, tr, sel);
         if (sel == ACT_TERM && ini_removed) last_it = 1;
         if ((i_iter == it_max && S.M == 1) || i_iter > it_max) last_it = 1;
         if (i_iter == it_max) sel = ACT_TERM;
@@ -2057,6 +2140,7 @@ DEV void gm_fit(const Blk &B, const FoldDev &F, const GmWork &W, int K, double l
         vk = blk_sum(B, a_part);
         err = fabs(vk - vk0) / S.M;
         residvar = 1 / (S.beta + 1e-10);
+        if (S.outer_log && B.tid == 0) { double *o = S.outer_log + 3 * (iter - 1); o[0] = err; o[1] = S.b; o[2] = residvar; }   // MainEff.c:196
     }
     CNT(c.n_outer = iter; c.m_final = S.M; if (S.M > c.m_max) c.m_max = S.M; c.status = S.status);
     blk_sync(B);

@@ -107,10 +107,12 @@ __device__ __forceinline__ double block_sum_256(double v, double *sh)
 
 // per column: scale = |x| (1 when 0), rscale, bt0 = x.y/scale, cs = x.1/scale
 // (elasticNetLinearNeMainEff.c:87-99 and the y- and 1-parts of :1171-1177)
-// phi (optional): the normalised column x / scale (the reference's PHI, :1608-1617), the u-operand of gram_kernel
+// phi (optional): the normalised column, the u-operand of gram_kernel, formed as the reference forms its PHI: a main-effect
+// column is scaled by the reciprocal of its norm (dscal with 1/Scales, :517-520, :1062-1065; Full2.c:530-535), a pair column is
+// divided by it (Full2.c:544, :913)
 __global__ void colstats_kernel(const double *__restrict__ X, const double *__restrict__ y, int N,
                                 double *__restrict__ scale, double *__restrict__ rscale,
-                                double *__restrict__ bt0, double *__restrict__ cs, double *__restrict__ phi)
+                                double *__restrict__ bt0, double *__restrict__ cs, double *__restrict__ phi, int n_main)
 {
     __shared__ double sh[16];
     const int j = blockIdx.x;
@@ -129,8 +131,9 @@ __global__ void colstats_kernel(const double *__restrict__ X, const double *__re
         scale[j] = s; rscale[j] = 1 / s; bt0[j] = xy / s; cs[j] = x1 / s;
     }
     if (phi) {
-        const double s = sqrt(q == 0 ? 1.0 : q);                // q is the same in every thread (block_sum_256)
-        for (int h = threadIdx.x; h < N; h += blockDim.x) phi[(size_t)j * N + h] = x[h] / s;
+        const double s = sqrt(q == 0 ? 1.0 : q), r = 1 / s;     // q is the same in every thread (block_sum_256)
+        if (j < n_main) for (int h = threadIdx.x; h < N; h += blockDim.x) phi[(size_t)j * N + h] = x[h] * r;
+        else for (int h = threadIdx.x; h < N; h += blockDim.x) phi[(size_t)j * N + h] = x[h] / s;
     }
 }
 
@@ -369,17 +372,20 @@ struct CvParams {
 #define LDS_POOL_DOUBLES 19456    // 152 KB of the CU's 160 KB: the blocked inverse keeps its M x 16 panel (pitch 18) in it up to M = 1040 (beyond: GmWork::Tn)
 #endif
 #define LDS_FIT_BYTES ((LDS_POOL_DOUBLES + 2 * BLK_MAX_WAVES) * 8 + 4 * BLK_MAX_WAVES * 4)
+#define BM_POOL_DOUBLES_HALF 9856  // two binomial workgroups per CU: 77 KB pool + scratch + static LDS each, under half of 160 KB
 extern __shared__ double lds_dyn[];
 
-__device__ inline Blk make_blk()
+#define LDS_BYTES_FOR(pool) (((pool) + 2 * BLK_MAX_WAVES) * 8 + 4 * BLK_MAX_WAVES * 4)
+
+__device__ inline Blk make_blk(int pool_n = LDS_POOL_DOUBLES)
 {
     Blk B;
     B.tid = threadIdx.x; B.nthr = blockDim.x;
     B.lane = threadIdx.x & 63;
     B.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     B.nwave = blockDim.x >> 6;
-    B.pool = lds_dyn; B.pool_n = LDS_POOL_DOUBLES;
-    B.red = lds_dyn + LDS_POOL_DOUBLES;
+    B.pool = lds_dyn; B.pool_n = pool_n;
+    B.red = lds_dyn + pool_n;
     B.ired = (int *)(B.red + 2 * BLK_MAX_WAVES);
     return B;
 }
@@ -536,6 +542,7 @@ struct BmCvParams {
     int K, n_folds, n_units;
     int epis, bmax;        // epistasis: NeFull.c rule set on the expanded design, at most bmax bases per model
     long long *phase;      // [n_units x PH_N] diagnostic ticks, may be null
+    int pool_n;            // doubles of the dynamic LDS pool this launch was given (two 256-thread workgroups per CU: half the CU's LDS each)
 };
 
 __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_EU) void bm_cv_kernel(BmCvParams P)
@@ -543,7 +550,7 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_EU) void bm_cv_kernel(Bm
     __shared__ int s_unit;
     __shared__ FitCounters s_cnt;
     __shared__ long long s_ph[PH_N];
-    const Blk B = make_blk();
+    const Blk B = make_blk(P.pool_n);
     BmWork W = bm_carve(P.ws + (size_t)blockIdx.x * P.L.bytes, P.K, P.L);
     W.phi_div = P.epis; W.bmax = P.bmax;
     for (;;) {
@@ -594,6 +601,8 @@ struct FitParams {
     GmVariant v;
     // helper workgroups (blocks 1..): the job board of the shared phases; null = the fit runs alone
     FsJob *jobs; int *active; int *queue; const FoldDev *folds; size_t ws_stride;
+    unsigned long long *trace; long long trace_cap;    // decision trace (pareben_set_trace); null = off
+    double *outer_log;                                 // verbose > 2: 3 doubles per outer iteration; null = off
 };
 
 // single Gaussian fit with the reference's .C outputs: elasticNetLinearNeMainEff.c:199-227 (Beta K x 4:
@@ -629,6 +638,7 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_EU) void gm_fit_kernel(F
     S.ph = s_ph;
     S.v = P.v;
     if (P.jobs) { S.share = &sh; S.fold = 0; }
+    S.trace = P.trace; S.trace_cap = P.trace_cap; S.outer_log = P.outer_log;
     gm_fit(B, P.F, W, K, P.lambda, P.alpha, S);
     if (threadIdx.x == 0 && P.active) AT_ADD(P.active, -1);        // the helpers may go (every path of the owner gets here)
     const int M = S.M, ld = W.ld;
@@ -667,6 +677,7 @@ struct BmFitParams {
     BmLayout L;
     int K;
     int epis, p, bmax;   // epistasis: K = p(p+1)/2 columns of the expanded design
+    double *outer_log;   // verbose > 2: 3 doubles per outer iteration; null = off
 };
 
 // single binomial fit with the reference's .C outputs: ElasticNetBinaryNEmainEff.c:346-389 (Beta K x 4 indexed by
@@ -684,6 +695,7 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_EU) void bm_fit_kernel(B
     GmScalars S;
     S.c = &s_cnt; S.ph = s_ph;
     S.v.epis = P.epis;
+    S.outer_log = P.outer_log;
     double ll;
     bm_fit(B, P.F, W, K, P.lambda, P.alpha, S, &ll);
     const int M = S.M, ld = W.ld;
@@ -912,7 +924,7 @@ static int ctx_create_impl(pareben_ctx **out, int device, const double *basis, i
         FoldDev &D = fd[f];
         D.X = H.X; D.y = H.y; D.Xte = H.Xte; D.yte = H.yte; D.scale = H.scale; D.rscale = H.rscale;
         D.bt0 = H.bt0; D.cs = H.cs; D.G = c->lazy ? c->d_rows : H.G; D.ymean = 0; D.varY = 0; D.N = H.N; D.nte = H.nte;
-        D.lazy = c->lazy; D.pool_rows = c->pool_rows; D.pool_base = f * c->pool_rows;
+        D.lazy = c->lazy; D.pool_rows = c->pool_rows; D.pool_base = f * c->pool_rows; D.n_main = p;
         D.slot_of = c->lazy ? c->d_lazy + c->lazy_hdr + (size_t)f * KF : nullptr;
         D.pool_next = c->lazy ? c->d_lazy + f : nullptr;
     }
@@ -951,7 +963,7 @@ static int prepare_folds(pareben_ctx *c)
         hipLaunchKernelGGL(gather_kernel, dim3((H.N + 255) / 256), dim3(256), 0, c->stream, c->d_y, H.d_tr, H.N, H.y);
         if (H.nte) hipLaunchKernelGGL(gather_kernel, dim3((H.nte + 255) / 256), dim3(256), 0, c->stream, c->d_y, H.d_te, H.nte, H.yte);
         hipLaunchKernelGGL(colstats_kernel, dim3(kf), dim3(256), 0, c->stream, H.X, H.y, H.N, H.scale, H.rscale, H.bt0, H.cs,
-                           H.G ? c->d_phi : (double *)nullptr);
+                           H.G ? c->d_phi : (double *)nullptr, p);
         hipLaunchKernelGGL(ystats_kernel, dim3(1), dim3(256), 0, c->stream, H.y, H.N, H.ystat);
         if (H.G) {                                  // 128 x 128 blocks, dealt to the XCDs in contiguous ranges of the row-major list
             const int nb = (kf + GB - 1) / GB;
@@ -1052,9 +1064,15 @@ static int run_enqueue(pareben_ctx *c, int n_cells, const double *alpha, const d
 
     int occ = 1;
     const bool binom = c->prior == PAREBEN_PRIOR_BINOMIAL;
+    // Binomial fits are chains of small dependent steps (Newton iterations with an M x M inverse, line searches, barriers:
+    // the matrix pipes of a CU are busy under a tenth of the time with one fit on it), so a CU runs TWO fits at once:
+    // 256-thread workgroups, each with half of the CU's LDS; the register budget per wave is unchanged (one wave per SIMD
+    // and workgroup).  PAREBEN_BM_THREADS=512 brings the one-fit-per-CU launch back (A/B runs).
+    int bm_threads = 256, bm_pool = BM_POOL_DOUBLES_HALF;
+    if (const char *e = getenv("PAREBEN_BM_THREADS")) { if (atoi(e) == 512) { bm_threads = 512; bm_pool = LDS_POOL_DOUBLES; } }
     if (binom) {
-        HIPCHK(hipFuncSetAttribute((const void *)bm_cv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FIT_BYTES));
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, bm_cv_kernel, FIT_THREADS, LDS_FIT_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void *)bm_cv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_FOR(bm_pool)));
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, bm_cv_kernel, bm_threads, LDS_BYTES_FOR(bm_pool)));
     } else {
         HIPCHK(hipFuncSetAttribute((const void *)gm_cv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FIT_BYTES));
         HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, gm_cv_kernel, FIT_THREADS, LDS_FIT_BYTES));
@@ -1114,15 +1132,15 @@ static int run_enqueue(pareben_ctx *c, int n_cells, const double *alpha, const d
         Q.folds = c->d_folds; Q.alpha = D.d_alpha; Q.lambda = D.d_lambda; Q.order = D.d_order; Q.queue = D.d_queue;
         Q.fold_err = D.d_err; Q.status = D.d_status; Q.counters = D.d_cnt; Q.ws = c->d_ws; Q.L = c->BL;
         Q.K = c->kfull; Q.n_folds = nF; Q.n_units = n_units; Q.phase = D.d_phase;
-        Q.epis = c->epis; Q.bmax = 2 * c->p;
-        hipLaunchKernelGGL(bm_cv_kernel, dim3(blocks), dim3(FIT_THREADS), LDS_FIT_BYTES, c->stream, Q);
+        Q.epis = c->epis; Q.bmax = 2 * c->p; Q.pool_n = bm_pool;
+        hipLaunchKernelGGL(bm_cv_kernel, dim3(blocks), dim3(bm_threads), LDS_BYTES_FOR(bm_pool), c->stream, Q);
     } else {
         hipLaunchKernelGGL(gm_cv_kernel, dim3(blocks), dim3(FIT_THREADS), LDS_FIT_BYTES, c->stream, P);
     }
     CK(hipGetLastError());
     CK(hipEventRecord(c->ev[2], c->stream));
 #undef CK
-    c->launch_info[0] = blocks; c->launch_info[1] = FIT_THREADS;
+    c->launch_info[0] = blocks; c->launch_info[1] = binom ? bm_threads : FIT_THREADS;
     c->launch_info[2] = binom ? c->BL.cap : c->cap;
     c->launch_info[4] = binom ? c->BL.cap : c->cap_ref;
     c->launch_info[3] = (int64_t)((binom ? c->BL.bytes : c->L.bytes) >> 10);
@@ -1448,9 +1466,26 @@ extern "C" int pareben_cv_grid_multi(const double *basis, int n, int p, const do
     return PAREBEN_OK;
 }
 
+// Diagnostics: the next pareben_fit_gaussian[_epis] calls of this thread record one TR_NSLOT-word record per inner
+// iteration (types.h TR_*: decision, margins, XOR hashes of the state) into buf: buf[0] = records written, records
+// from buf + TR_NSLOT; at most max_records.  NULL switches it off.  tools/trace_divergence.py compares it with the
+// oracle's trace of the same fit.
+static thread_local uint64_t *g_trace_buf = nullptr;
+static thread_local int64_t g_trace_cap = 0;
+extern "C" int pareben_set_trace(uint64_t *buf, int64_t max_records)
+{
+    if (buf && max_records < 1) return fail(PAREBEN_EINVAL, "bad argument");
+    g_trace_buf = buf; g_trace_cap = buf ? max_records : 0;
+    return PAREBEN_OK;
+}
+
 // one fit on all rows: a pseudo-fold whose training set is every row and whose held-out set is empty
+// `verbose`: the reference's Rprintf trace, printed to stdout after the launch from what the kernel recorded --
+// level > 0 basisMax and "outer loop starts" (MainEff.c:70, :139), > 1 the start / finish lines (:71, :205; binomial
+// NEmainEff.c:327, :352), > 2 one line per outer iteration (:196; binomial :342), > 4 one line per inner iteration
+// (:405) from the decision trace (Gaussian only).
 static int fit_one(int prior, int epis, const double *basis, const double *target, double lambda, double alpha,
-                   int n, int k, int device, double *Beta, double *scalars_out, int n_scalars, int64_t *counters)
+                   int n, int k, int device, double *Beta, double *scalars_out, int n_scalars, int64_t *counters, int verbose = 0)
 {
     std::vector<std::vector<int>> tr(1), te(1);
     tr[0].resize(n);
@@ -1467,8 +1502,11 @@ static int fit_one(int prior, int epis, const double *basis, const double *targe
     const int ncol = (epis && prior == PAREBEN_PRIOR_GAUSSIAN) ? 5 : 4;
     const size_t KF = (epis && prior == PAREBEN_PRIOR_BINOMIAL) ? (size_t)2 * k : (size_t)c->kfull;     // rows of the Beta table
     double *d_beta = nullptr, *d_sc = nullptr; int *d_st = nullptr; long long *d_cnt = nullptr;
-    FsJob *d_jobs = nullptr; int *d_flags = nullptr;
-    auto cleanup = [&]() { hipFree(d_beta); hipFree(d_sc); hipFree(d_st); hipFree(d_cnt); hipFree(d_jobs); hipFree(d_flags); };
+    FsJob *d_jobs = nullptr; int *d_flags = nullptr; unsigned long long *d_trace = nullptr; double *d_olog = nullptr;
+    auto cleanup = [&]() { hipFree(d_beta); hipFree(d_sc); hipFree(d_st); hipFree(d_cnt); hipFree(d_jobs); hipFree(d_flags); hipFree(d_trace); hipFree(d_olog); };
+    std::vector<uint64_t> vtrace;                              // verbose > 4 without a caller's trace buffer: an internal one
+    uint64_t *trace_host = g_trace_buf; int64_t trace_cap = g_trace_cap;
+    if (verbose > 4 && !trace_host && prior == PAREBEN_PRIOR_GAUSSIAN) { trace_cap = 20000; vtrace.assign((size_t)TR_NSLOT * (trace_cap + 1), 0); trace_host = vtrace.data(); }
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return bail(fail(PAREBEN_EHIP, #x, e_)); } } while (0)
     CK(dmalloc(&d_beta, KF * ncol)); CK(dmalloc(&d_sc, (size_t)4)); CK(dmalloc(&d_st, (size_t)1));
     CK(dmalloc(&d_cnt, (size_t)PAREBEN_NCOUNTERS));
@@ -1480,6 +1518,13 @@ static int fit_one(int prior, int epis, const double *basis, const double *targe
         P.F = F; P.lambda = lambda; P.alpha = alpha; P.Beta = d_beta; P.scalars = d_sc; P.status = d_st; P.counters = d_cnt;
         P.ws = c->d_ws; P.offK = c->L.offK; P.offSig = c->L.offSig; P.offM = c->L.offM; P.K = c->kfull; P.cap = c->cap; P.cap_flag = c->cap_ref;
         P.p = k; P.v = c->variant;
+        P.trace = nullptr; P.trace_cap = 0; P.outer_log = nullptr;
+        if (trace_host) {
+            CK(dmalloc(&d_trace, (size_t)TR_NSLOT * (trace_cap + 1)));
+            CK(hipMemset(d_trace, 0, sizeof(unsigned long long) * TR_NSLOT * (trace_cap + 1)));
+            P.trace = d_trace; P.trace_cap = trace_cap;
+        }
+        if (verbose > 2) { CK(dmalloc(&d_olog, (size_t)300)); CK(hipMemset(d_olog, 0, sizeof(double) * 300)); P.outer_log = d_olog; }
         CK(hipFuncSetAttribute((const void *)gm_fit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FIT_BYTES));
         // helpers: as many workgroups as are resident at once (they wait for the owner, so none may be left undispatched
         // in front of it); PAREBEN_SHARE=0 runs the fit alone
@@ -1502,6 +1547,8 @@ static int fit_one(int prior, int epis, const double *basis, const double *targe
         BmFitParams P;
         P.F = F; P.lambda = lambda; P.alpha = alpha; P.Beta = d_beta; P.scalars = d_sc; P.status = d_st; P.counters = d_cnt;
         P.ws = c->d_ws; P.L = c->BL; P.K = c->kfull; P.epis = epis; P.p = k; P.bmax = 2 * k;
+        P.outer_log = nullptr;
+        if (verbose > 2) { CK(dmalloc(&d_olog, (size_t)300)); CK(hipMemset(d_olog, 0, sizeof(double) * 300)); P.outer_log = d_olog; }
         CK(hipFuncSetAttribute((const void *)bm_fit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FIT_BYTES));
         hipLaunchKernelGGL(bm_fit_kernel, dim3(1), dim3(FIT_THREADS), LDS_FIT_BYTES, c->stream, P);
     }
@@ -1512,6 +1559,31 @@ static int fit_one(int prior, int epis, const double *basis, const double *targe
     CK(hipMemcpy(sc, d_sc, sizeof sc, hipMemcpyDeviceToHost));
     CK(hipMemcpy(&st, d_st, sizeof st, hipMemcpyDeviceToHost));
     if (counters) CK(hipMemcpy(counters, d_cnt, sizeof(int64_t) * PAREBEN_NCOUNTERS, hipMemcpyDeviceToHost));
+    if (d_trace) CK(hipMemcpy(trace_host, d_trace, sizeof(unsigned long long) * TR_NSLOT * (trace_cap + 1), hipMemcpyDeviceToHost));
+    if (verbose > 0) {
+        int64_t cn[PAREBEN_NCOUNTERS];
+        double olog[300] = {0};
+        CK(hipMemcpy(cn, d_cnt, sizeof cn, hipMemcpyDeviceToHost));
+        if (d_olog) CK(hipMemcpy(olog, d_olog, sizeof olog, hipMemcpyDeviceToHost));
+        const bool gauss = prior == PAREBEN_PRIOR_GAUSSIAN;
+        if (gauss) printf("basisMax: %d", c->cap_ref);
+        if (verbose > 1) printf(gauss ? "start EB-elasticNet with alpha: %f, lambda: %f\n" : "Empirical Bayesian Elastic Net outer loop starts\n", alpha, lambda);
+        if (gauss) printf("outer loop starts");
+        size_t r = 0;
+        const size_t n_rec = (trace_host && verbose > 4) ? (size_t)trace_host[0] : 0;
+        for (int it = 1; it <= (int)cn[0]; it++) {
+            for (; r < n_rec && (int)trace_host[TR_NSLOT * (r + 1) + TR_ITER] == it; r++) {
+                const uint64_t *t = trace_host + TR_NSLOT * (r + 1);
+                printf("\t inner loop %d; number of basis: %d \t actionStatus: %d \tnu: %d\n", (int)t[TR_IITER], (int)t[TR_MAFTER], (int)(int64_t)t[TR_SEL], (int)(int64_t)t[TR_NU] + 1);
+            }
+            if (verbose > 2) {
+                if (gauss) printf("Iteration number: %d, err: %f;\t mu: %f\tsigma0:%f.\n", it, olog[3 * (it - 1)], olog[3 * (it - 1) + 1], olog[3 * (it - 1) + 2]);
+                else printf("Iteration number: %d, err: %f\n", it, olog[3 * (it - 1)]);
+            }
+        }
+        if (verbose > 1) printf("EBEN Finished, number of basis: %d\n", (int)cn[9]);
+        fflush(stdout);
+    }
 #undef CK
     for (int i = 0; i < n_scalars; i++) scalars_out[i] = sc[i];
     cleanup();
@@ -1523,10 +1595,9 @@ extern "C" int pareben_fit_gaussian(const double *basis, const double *target, d
                                     double *Beta, double *wald, double *intercept, int n, int k,
                                     int verbose, double *residual, int device, int64_t *counters)
 {
-    (void)verbose;
     if (!basis || !target || !Beta || !wald || !intercept || !residual || n < 2 || k < 1) return fail(PAREBEN_EINVAL, "bad argument");
     double sc[3];
-    const int rc = fit_one(PAREBEN_PRIOR_GAUSSIAN, 0, basis, target, lambda, alpha, n, k, device, Beta, sc, 3, counters);
+    const int rc = fit_one(PAREBEN_PRIOR_GAUSSIAN, 0, basis, target, lambda, alpha, n, k, device, Beta, sc, 3, counters, verbose);
     if (rc == PAREBEN_OK) { *wald = sc[0]; *intercept = sc[1]; *residual = sc[2]; }
     return rc;
 }
@@ -1535,11 +1606,10 @@ extern "C" int pareben_fit_gaussian_epis(const double *basis, const double *targ
                                          double *Beta, double *wald, double *intercept, int n, int k,
                                          int verbose, double *residual, int device, int64_t *counters)
 {
-    (void)verbose;
     if (!basis || !target || !Beta || !wald || !intercept || !residual || n < 2 || k < 2) return fail(PAREBEN_EINVAL, "bad argument");
     if ((long long)k * (k + 1) / 2 > 2000000000LL) return fail(PAREBEN_EINVAL, "too many pairwise columns");
     double sc[3];
-    const int rc = fit_one(PAREBEN_PRIOR_GAUSSIAN, 1, basis, target, lambda, alpha, n, k, device, Beta, sc, 3, counters);
+    const int rc = fit_one(PAREBEN_PRIOR_GAUSSIAN, 1, basis, target, lambda, alpha, n, k, device, Beta, sc, 3, counters, verbose);
     if (rc == PAREBEN_OK) { *wald = sc[0]; *intercept = sc[1]; *residual = sc[2]; }
     return rc;
 }
@@ -1548,10 +1618,10 @@ extern "C" int pareben_fit_binomial(const double *basis, const double *target, d
                                     double *logLikelihood, double *Beta, double *wald, double *intercept,
                                     int n, int k, int verbose, int bMax, int device, int64_t *counters)
 {
-    (void)verbose; (void)bMax;
+    (void)bMax;
     if (!basis || !target || !Beta || !wald || !intercept || !logLikelihood || n < 2 || k < 1) return fail(PAREBEN_EINVAL, "bad argument");
     double sc[4];
-    const int rc = fit_one(PAREBEN_PRIOR_BINOMIAL, 0, basis, target, lambda, alpha, n, k, device, Beta, sc, 4, counters);
+    const int rc = fit_one(PAREBEN_PRIOR_BINOMIAL, 0, basis, target, lambda, alpha, n, k, device, Beta, sc, 4, counters, verbose);
     if (rc == PAREBEN_OK) { *logLikelihood = sc[0]; *wald = sc[1]; intercept[0] = sc[2]; intercept[1] = sc[3]; }
     return rc;
 }
@@ -1560,14 +1630,58 @@ extern "C" int pareben_fit_binomial_epis(const double *basis, const double *targ
                                          double *logLikelihood, double *Beta, double *wald, double *intercept,
                                          int n, int k, int verbose, int bMax, int device, int64_t *counters)
 {
-    (void)verbose;
     if (!basis || !target || !Beta || !wald || !intercept || !logLikelihood || n < 2 || k < 2) return fail(PAREBEN_EINVAL, "bad argument");
     if (bMax != 2 * k) return fail(PAREBEN_EINVAL, "bMax must be 2*k, what EBelasticNet.Binomial passes (Beta is bMax x 4)");
     if ((long long)k * (k + 1) / 2 > 2000000000LL) return fail(PAREBEN_EINVAL, "too many pairwise columns");
     double sc[4];
-    const int rc = fit_one(PAREBEN_PRIOR_BINOMIAL, 1, basis, target, lambda, alpha, n, k, device, Beta, sc, 4, counters);
+    const int rc = fit_one(PAREBEN_PRIOR_BINOMIAL, 1, basis, target, lambda, alpha, n, k, device, Beta, sc, 4, counters, verbose);
     if (rc == PAREBEN_OK) { *logLikelihood = sc[0]; *wald = sc[1]; intercept[0] = sc[2]; intercept[1] = sc[3]; }
     return rc;
+}
+
+// ------------------------------------------------------------------------------------------
+// The reference's own .C entry points: same symbol names, argument order and pointer-only calling convention as
+// EBEN_orig/src (R's .C passes every argument as a pointer and ignores the return value), so that
+// .C("elasticNetLinearNeMainEff", ..., PACKAGE = "pareben_hip") in EBelasticNet.Gaussian / .Binomial binds them with
+// nothing but PACKAGE changed.  Outputs are written in place.  .C has no error channel: on failure the message goes
+// to stderr and the scalar outputs are set to NaN (the reference carries on into undefined behaviour instead).
+// Device: PAREBEN_DEVICE (default 0).
+static int dotc_device(void) { const char *e = getenv("PAREBEN_DEVICE"); return e ? atoi(e) : 0; }
+static void dotc_failed(const char *entry, double *a, double *b, double *c2)
+{
+    fprintf(stderr, "%s: %s\n", entry, pareben_last_error());
+    const double nan = __builtin_nan("");
+    if (a) *a = nan; if (b) *b = nan; if (c2) *c2 = nan;
+}
+// EBEN_orig/src/elasticNetLinearNeMainEff.c:55-57, called from EBEN_orig/R/EBelasticNet.Gaussian.R:38-51
+extern "C" void elasticNetLinearNeMainEff(double *BASIS, double *y, double *a_lambda, double *b_Alpha, double *Beta,
+                                          double *wald, double *intercept, int *n, int *kdim, int *verb, double *residual)
+{
+    if (pareben_fit_gaussian(BASIS, y, *a_lambda, *b_Alpha, Beta, wald, intercept, *n, *kdim, verb ? *verb : 0, residual, dotc_device(), nullptr))
+        dotc_failed("elasticNetLinearNeMainEff", wald, intercept, residual);
+}
+// EBEN_orig/src/elasticNetLinearNeFull2.c:57-58, called from EBEN_orig/R/EBelasticNet.Gaussian.R:16-29
+extern "C" void elasticNetLinearNeEpisEff(double *BASIS, double *y, double *a_lambda, double *b_Alpha, double *Beta,
+                                          double *wald, double *intercept, int *n, int *kdim, int *VB, double *residual)
+{
+    if (pareben_fit_gaussian_epis(BASIS, y, *a_lambda, *b_Alpha, Beta, wald, intercept, *n, *kdim, VB ? *VB : 0, residual, dotc_device(), nullptr))
+        dotc_failed("elasticNetLinearNeEpisEff", wald, intercept, residual);
+}
+// EBEN_orig/src/ElasticNetBinaryNEmainEff.c:236-238, called from EBEN_orig/R/EBelasticNet.Binomial.R:32-46
+extern "C" void ElasticNetBinaryNEmainEff(double *BASIS, double *Targets, double *a_Lambda, double *b_Alpha, double *logLIKELIHOOD,
+                                          double *Beta, double *wald, double *intercept, int *n, int *kdim, int *VB, int *bMax)
+{
+    if (pareben_fit_binomial(BASIS, Targets, *a_Lambda, *b_Alpha, logLIKELIHOOD, Beta, wald, intercept, *n, *kdim, VB ? *VB : 0,
+                             bMax ? *bMax : *kdim, dotc_device(), nullptr))
+        dotc_failed("ElasticNetBinaryNEmainEff", logLIKELIHOOD, wald, intercept);
+}
+// EBEN_orig/src/ElasticNetBinaryNeFull.c:52-55, called from EBEN_orig/R/EBelasticNet.Binomial.R:10-24
+extern "C" void ElasticNetBinaryNEfull(double *BASIS, double *Targets, double *a_Lambda, double *b_Alpha, double *logLIKELIHOOD,
+                                       double *Beta, double *wald, double *intercept, int *n, int *kdim, int *VB, int *bMax)
+{
+    if (pareben_fit_binomial_epis(BASIS, Targets, *a_Lambda, *b_Alpha, logLIKELIHOOD, Beta, wald, intercept, *n, *kdim, VB ? *VB : 0,
+                                  bMax ? *bMax : 2 * *kdim, dotc_device(), nullptr))
+        dotc_failed("ElasticNetBinaryNEfull", logLIKELIHOOD, wald, intercept);
 }
 
 #ifdef PAREBEN_DIAG

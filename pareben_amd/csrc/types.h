@@ -23,6 +23,8 @@ struct FoldDev {
     double ymean;           // sum(y)/N                                       MainEff.c:145-147
     double varY;            // unbiased variance of y                         MainEff.c:152
     int N, nte;
+    int n_main;             // columns 0 .. n_main-1 are main effects: PHI = x * (1/scale) (MainEff.c:1062-1065, :517-520); the pair
+                            // columns behind them (epistasis) are formed by division, PHI = x / scale (Full2.c:544, :913)
 };
 
 // The two Gaussian reference kernels share their skeleton; these are the constants and rules in
@@ -51,6 +53,13 @@ enum {
     ST_STALE = 4,         // reference's stale-index delete path taken (SURVEY.md hard parts)
     ST_ABORT = 8          // fit stopped early (a state the reference leaves undefined)
 };
+
+// Decision trace (diagnostics; pareben_set_trace, tools/trace_divergence.py): one record of TR_NSLOT 64-bit words per
+// inner iteration -- what was decided, by what margin, and order-free XOR hashes of the state afterwards.  The oracle
+// writes the same layout (oracle/eben_gm.c), so two builds can be compared record by record.  buf[0] = records
+// written; records start at buf + TR_NSLOT.
+enum { TR_ITER, TR_IITER, TR_MBEFORE, TR_NU, TR_ACT, TR_NTODO, TR_SEL, TR_MAFTER,
+       TR_BEST, TR_SECOND, TR_CUTOFF, TR_NEAREST, TR_BETA, TR_HSIN, TR_HQIN, TR_HSIG, TR_NSLOT };
 
 #define ADD_TB 16         // consecutive ADD actions of one block update applied with ONE sweep of the Gram rows
 

@@ -16,14 +16,16 @@
 
 namespace {
 struct Fold {
-    int N, nte;
+    int N, nte, n_main;
     std::vector<double> X, y, Xte, yte, scale, rscale, bt0, cs, G;
     double ymean, varY;
 };
 
 // CPU stand-ins for split_kernel / colstats_kernel / ystats_kernel / gram_kernel
-void prepare(Fold &F, const double *basis, int n, int p, const double *y, const int *fold_id, int f)
+void prepare(Fold &F, const double *basis, int n, int p, const double *y, const int *fold_id, int f, int n_main = -1)
 {
+    if (n_main < 0) n_main = p;
+    F.n_main = n_main;
     std::vector<int> tr, te;
     for (int i = 0; i < n; i++) (fold_id[i] == f + 1 ? te : tr).push_back(i);
     F.N = (int)tr.size(); F.nte = (int)te.size();
@@ -49,7 +51,8 @@ void prepare(Fold &F, const double *basis, int n, int p, const double *y, const 
     for (int u = 0; u < p; u++)
         for (int i = 0; i < p; i++) {
             double a = 0;
-            for (int h = 0; h < F.N; h++) a += F.X[(size_t)i * F.N + h] * (F.X[(size_t)u * F.N + h] * F.rscale[u]);
+            if (u < n_main) for (int h = 0; h < F.N; h++) a += F.X[(size_t)i * F.N + h] * (F.X[(size_t)u * F.N + h] * F.rscale[u]);
+            else for (int h = 0; h < F.N; h++) a += F.X[(size_t)i * F.N + h] * (F.X[(size_t)u * F.N + h] / F.scale[u]);
             F.G[(size_t)u * p + i] = a / F.scale[i];
         }
 }
@@ -59,7 +62,7 @@ FoldDev dev_view(const Fold &F)
     FoldDev D;
     D.X = F.X.data(); D.y = F.y.data(); D.Xte = F.Xte.data(); D.yte = F.yte.data();
     D.scale = F.scale.data(); D.rscale = F.rscale.data(); D.bt0 = F.bt0.data(); D.cs = F.cs.data();
-    D.G = F.G.data(); D.ymean = F.ymean; D.varY = F.varY; D.N = F.N; D.nte = F.nte;
+    D.G = F.G.data(); D.ymean = F.ymean; D.varY = F.varY; D.N = F.N; D.nte = F.nte; D.n_main = F.n_main;
     D.slot_of = nullptr; D.pool_next = nullptr; D.pool_base = 0; D.pool_rows = 0; D.lazy = 0;
     return D;
 }
@@ -119,7 +122,7 @@ static int emul_gauss_grid(const double *basis_in, int n, int p_in, const double
         cap = std::min(std::min(cap, p), 2048);
     }
     std::vector<Fold> folds(n_folds);
-    for (int f = 0; f < n_folds; f++) prepare(folds[f], basis, n, p, y, fold_id, f);
+    for (int f = 0; f < n_folds; f++) prepare(folds[f], basis, n, p, y, fold_id, f, p_in);
     Work ws(p, cap);
     int ired[4];
     Blk B; B.tid = 0; B.nthr = 1; B.lane = 0; B.wave = 0; B.nwave = 1; B.red = nullptr; B.ired = ired; B.pool = nullptr; B.pool_n = 0;
@@ -166,6 +169,11 @@ extern "C" int emul_gf_cv_grid(const double *basis, int n, int p, const double *
                                double *fold_err, int *status, long long *counters)
 { return emul_gauss_grid(basis, n, p, y, fold_id, n_folds, alpha, lambda, n_cells, 1, fold_err, status, counters); }
 
+// decision trace of the following emul_gm_fit calls (same layout as pareben_set_trace / eben_set_trace)
+static unsigned long long *g_trace = nullptr;
+static long long g_trace_cap = 0;
+extern "C" void emul_set_trace(unsigned long long *buf, long long max_records) { g_trace = buf; g_trace_cap = max_records; if (buf) buf[0] = 0; }
+
 // one fit on all rows; out = {intercept, beta(noise precision), M}; used/mu sized >= cap
 extern "C" int emul_gm_fit(const double *X, const double *y, int n, int p, double lambda, double alpha,
                            double *out, int *used, double *mu, double *sigdiag, long long *counters)
@@ -177,6 +185,7 @@ extern "C" int emul_gm_fit(const double *X, const double *y, int n, int p, doubl
     Blk B; B.tid = 0; B.nthr = 1; B.lane = 0; B.wave = 0; B.nwave = 1; B.red = nullptr; B.ired = nullptr; B.pool = nullptr; B.pool_n = 0;
     FoldDev D = dev_view(F);
     GmScalars S; FitCounters cnt; S.c = &cnt; S.ph = nullptr; S.v = GmVariant{0, 0.9, 0.001, 1e-3, 1e2, 1e-10};
+    S.trace = g_trace; S.trace_cap = g_trace_cap;
     gm_fit(B, D, ws.W, p, lambda, alpha, S);
     out[0] = S.b; out[1] = S.beta; out[2] = S.M;
     for (int i = 0; i < S.M; i++) { used[i] = ws.W.used[i]; mu[i] = ws.W.mu[i] / F.scale[ws.W.used[i]]; sigdiag[i] = ws.W.Sig[(size_t)i * cap + i] / (F.scale[ws.W.used[i]] * F.scale[ws.W.used[i]]); }

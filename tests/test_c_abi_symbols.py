@@ -12,7 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared():
     txt = open(os.path.join(ROOT, "include", "pareben_hip.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(pareben_[a-z_]+)\s*\(", txt)))
+    dotc = re.findall(r"\bvoid\s+([A-Za-z]+)\s*\(", txt)          # the reference's own .C symbols
+    return sorted(set(re.findall(r"\b(pareben_[a-z_]+)\s*\(", txt)) | set(dotc))
 
 
 def test_header_symbols_exported():
@@ -21,7 +22,8 @@ def test_header_symbols_exported():
     names = _declared()
     assert {"pareben_ctx_create", "pareben_ctx_run", "pareben_ctx_destroy", "pareben_cv_grid", "pareben_cv_grid_multi",
             "pareben_lambda_max_pairs", "pareben_fit_gaussian", "pareben_fit_gaussian_epis", "pareben_fit_binomial",
-            "pareben_fit_binomial_epis", "pareben_ctx_gram", "pareben_version", "pareben_last_error"} <= set(names)
+            "pareben_fit_binomial_epis", "pareben_ctx_gram", "pareben_version", "pareben_last_error", "pareben_set_trace",
+            "elasticNetLinearNeMainEff", "elasticNetLinearNeEpisEff", "ElasticNetBinaryNEmainEff", "ElasticNetBinaryNEfull"} <= set(names)
     for n in names:
         assert hasattr(L, n), n
     assert b"gfx950" in L.pareben_version()
