@@ -105,7 +105,8 @@ def gm_algorithmic(cnt, K, np):
     c = cnt.reshape(-1, cnt.shape[-1]).astype(np.float64).sum(axis=0)
     n_outer, n_inner, n_add, n_del, n_reest, n_full, sm_act, sm_full, sm2_full = c[:9]
     n_act = n_add + n_del + n_reest
-    bytes_ = 8.0 * K * (sm_act + n_add + sm_full + 6.0 * n_inner + 4.0 * n_act + 3.0 * n_outer)
+    sm_swept = c[13] if len(c) > 13 else sm_act        # rows the action sweeps really read (a sweep that a full-stat pass overtakes is never run)
+    bytes_ = 8.0 * K * (sm_swept + n_add + sm_full + 6.0 * n_inner + 4.0 * n_act + 3.0 * n_outer)
     flops_nominal = 2.0 * K * sm2_full + 2.0 * K * sm_act + 30.0 * K * n_inner
     mfma_flops = 8192.0 * c[12]
     return bytes_, flops_nominal, mfma_flops

@@ -54,8 +54,9 @@ extern "C" {
 
 /* number of int64 counters per fit in counters[] (order: n_outer, n_inner, n_add, n_del,
  * n_reest, n_fullstat, sum_m_action, sum_m_full, sum_m2_full, m_final, m_max, status, mfma_tiles =
- * 16x16x16 tile products (8192 flop each) executed on the FP64 matrix cores for this fit) */
-#define PAREBEN_NCOUNTERS 13
+ * 16x16x16 tile products (8192 flop each) executed on the FP64 matrix cores for this fit, sum_m_swept = Gram rows
+ * the action sweeps really read: sum_m_action less the sweeps a following full-stat pass made unnecessary) */
+#define PAREBEN_NCOUNTERS 14
 
 typedef struct pareben_ctx pareben_ctx;
 

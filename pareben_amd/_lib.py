@@ -7,9 +7,9 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PAREBEN_LIB=<path> loads another build of the same library (A/B timing of kernel variants, diagnostic builds)
 LIB_PATH = os.environ.get("PAREBEN_LIB") or os.path.join(_HERE, "lib", "libpareben_hip.so")
-NCOUNTERS = 13
+NCOUNTERS = 14
 COUNTER_NAMES = ("n_outer", "n_inner", "n_add", "n_del", "n_reest", "n_fullstat", "sum_m_action",
-                 "sum_m_full", "sum_m2_full", "m_final", "m_max", "status", "mfma_tiles")
+                 "sum_m_full", "sum_m2_full", "m_final", "m_max", "status", "mfma_tiles", "sum_m_swept")
 ST_OVERFLOW, ST_CHOLESKY, ST_STALE, ST_ABORT = 1, 2, 4, 8
 
 _lib = None

@@ -67,6 +67,11 @@ struct GmScalars {
     int gc_ok = 0;     // Gaussian, device: the Gram block cache W.Gc matches the active set's slots (0 = rebuild at the next Hessian)
     unsigned long long *trace = nullptr;   // decision trace (types.h TR_*; null = off), trace_cap records
     long long trace_cap = 0;
+    // The K-space half (Gram-row sweep + S_in / Q_in update) of the LAST unit of a block of actions, held back until the
+    // iteration knows whether a full-stat pass follows (which recomputes S_in / Q_in from scratch and makes the sweep
+    // dead work): gm_inner.  kind: 0 none, 1 re-estimate, 2 single add, 3 delete, 4 run of adds.
+    struct Pending { int kind = 0, M = 0, T = 0, jj = -1, row = -1; double beta = 0, c1 = 0, c2 = 0; } pend;
+    int defer = 1;
     double *outer_log = nullptr;           // per-fit entries with verbose > 2: (err, intercept | -, residual variance | -) per outer iteration
 };
 #define CNT(stmt) do { if (B.tid == 0) { FitCounters &c = *S.c; stmt; } } while (0)
@@ -447,7 +452,7 @@ DEV int fs_claim(FsJob *job, int n_tiles, int chunk)
 // Owner side.  Returns false when sharing is off / not worth it (the caller then does the whole phase);
 // otherwise opens the job, runs work(tile0, tile1) on the chunks it claims itself, waits for the rest.
 template <class Work>
-DEV bool job_share(const Blk &B, GmScalars &S, int kind, int M, int n_tiles, double beta, int mode, int rid, double c1,
+DEV bool job_share(const Blk &B, GmScalars &S, int kind, int M, int n_tiles, double beta, int mode, int rid, int aux, double c1,
                    double c2, Work work)
 {
     const FsShare *sh = S.share;
@@ -466,7 +471,7 @@ DEV bool job_share(const Blk &B, GmScalars &S, int kind, int M, int n_tiles, dou
     __syncthreads();
     if (B.tid == 0) {
         AT_STORE(&job->done, 0); AT_STORE(&job->fold, S.fold); AT_STORE(&job->M, M); AT_STORE(&job->n_tiles, n_tiles);
-        AT_STORE(&job->kind, kind); AT_STORE(&job->mode, mode); AT_STORE(&job->rid, rid);
+        AT_STORE(&job->kind, kind); AT_STORE(&job->mode, mode); AT_STORE(&job->rid, rid); AT_STORE(&job->pad, aux);
         __hip_atomic_store(&job->beta, beta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&job->c1, c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&job->c2, c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -518,7 +523,7 @@ DEVNI void gm_fullstat_pass(const Blk &B, const FoldDev &F, const GmWork &W, int
     const int n_tiles = 1;                                    // the host build has no tiles: one call does all features
 #else
     const int n_tiles = (K + FS_FT - 1) / FS_FT;
-    if (M >= 48 && job_share(B, S, JOB_FULLSTAT, M, n_tiles, beta, 0, -1, 0.0, 0.0,
+    if (M >= 48 && job_share(B, S, JOB_FULLSTAT, M, n_tiles, beta, 0, -1, -1, 0.0, 0.0,
                              [&](int t0, int t1) { gm_fullstat_features(B, F, W, K, M, beta, t0, t1); })) return;
 #endif
     gm_fullstat_features(B, F, W, K, M, beta, 0, n_tiles);
@@ -771,36 +776,50 @@ DEV void gm_sq_core(gptr_cc G, lptr_d lvec, lptr_i lused, const GmWork &W, int K
         }
     }
 }
+// The vector and the Gram row ids of the M rows of a sweep -> LDS.  A delete whose sweep was held back (gm_inner) runs
+// after its slot shuffle: `del_jj` >= 0 names the freed slot and `del_row` the Gram row that sat there; the row that
+// moved into it goes back to the end of the list.
+DEV void gm_sq_stage(const Blk &B, const GmWork &W, int M, const double *vec, lptr_d lvec, lptr_i lused, int del_jj, int del_row)
+{
+    blk_sync(B);
+    for (int j = B.tid; j < M; j += B.nthr) {
+        lvec[j] = vec[j];
+        int r = W.rowid[j];
+        if (del_jj >= 0) { if (j == del_jj) r = del_row; else if (j == M - 1) r = W.rowid[del_jj]; }
+        lused[j] = r;
+    }
+    blk_sync(B);
+}
 // stage row ids and the vector in LDS, then tiles [t0, t1) of 128 features with one pair per thread
 // (the shape a claimed chunk has: owner and helpers)
 DEV void gm_sq_tiles(const Blk &B, const FoldDev &F, const GmWork &W, int K, int M, const double *vec, int mode, double beta,
-                     double c1, double c2, const double *newrow, int t0, int t1, bool stage)
+                     double c1, double c2, const double *newrow, int t0, int t1, bool stage, int del_jj = -1, int del_row = -1)
 {
     const gptr_cc G = (gptr_cc)as_global(uni_ptr(F.G));
     const lptr_d lvec = as_lds(B.pool);
     const lptr_i lused = as_lds((int *)(B.pool + ((M + 1) & ~1)));
     const int tid = B.tid, nthr = uni(B.nthr);
-    if (stage) {
-        blk_sync(B);
-        for (int j = tid; j < M; j += nthr) { lvec[j] = vec[j]; lused[j] = W.rowid[j]; }
-        blk_sync(B);
-    }
+    if (stage) gm_sq_stage(B, W, M, vec, lvec, lused, del_jj, del_row);
     const int Kp = K & ~1, f0 = t0 * SQ_FT, f1 = t1 * SQ_FT < Kp ? t1 * SQ_FT : Kp;
     gm_sq_core<1, 8>(G, lvec, lused, W, uni(K), uni(M), mode, beta, c1, c2, newrow, f0, f1, tid, nthr);
 }
 #endif
 
 // a[i] = sum_j G[used[j], i] * vec[j] for all features, fused with the S_in/Q_in update that
-// consumes it.  `rid`: Gram row id of the new feature (mode 1), else -1.
+// consumes it.  `rid`: Gram row id of the new feature (mode 1), else -1.  del_jj / del_row: see gm_sq_stage.
 DEVNI void gm_sq_update(const Blk &B, const FoldDev &F, const GmWork &W, int K, int M, const double *vec,
-                        int mode, double beta, double c1, double c2, int rid, GmScalars &S)
+                        int mode, double beta, double c1, double c2, int rid, GmScalars &S, int del_jj = -1, int del_row = -1)
 {
     const double *newrow = rid >= 0 ? F.G + (size_t)rid * K : nullptr;
+    CNT(c.sum_m_swept += M);
 #ifdef PAREBEN_HOST_EMUL
-    (void)S;
     PAR(i, K) {
         double a = 0;
-        for (int j = 0; j < M; j++) a += F.G[(size_t)W.rowid[j] * K + i] * vec[j];
+        for (int j = 0; j < M; j++) {
+            int r = W.rowid[j];
+            if (del_jj >= 0) { if (j == del_jj) r = del_row; else if (j == M - 1) r = W.rowid[del_jj]; }
+            a += F.G[(size_t)r * K + i] * vec[j];
+        }
         gm_sq_apply(W, mode, beta, c1, c2, newrow, i, a);
     }
 #else
@@ -810,12 +829,11 @@ DEVNI void gm_sq_update(const Blk &B, const FoldDev &F, const GmWork &W, int K, 
     const lptr_i lused = as_lds((int *)(B.pool + ((M + 1) & ~1)));
     const int tid = B.tid, nthr = uni(B.nthr);
     K = uni(K); M = uni(M);
-    blk_sync(B);
-    for (int j = tid; j < M; j += nthr) { lvec[j] = vec[j]; lused[j] = W.rowid[j]; }
-    blk_sync(B);
+    gm_sq_stage(B, W, M, vec, lvec, lused, del_jj, del_row);
     const int Kp = K & ~1;                                    // pairs cover [0, Kp); an odd last feature is handled below
     const int n_tiles = (Kp + SQ_FT - 1) / SQ_FT;
-    const bool shared = M >= 96 && job_share(B, S, JOB_SQ, M, n_tiles, beta, mode, rid, c1, c2, [&](int t0, int t1) {
+    // the job carries (mode, rid | the deleted slot's Gram row, the deleted slot) so that a helper stages the same rows
+    const bool shared = M >= 96 && job_share(B, S, JOB_SQ, M, n_tiles, beta, mode, mode == 2 ? del_row : rid, del_jj, c1, c2, [&](int t0, int t1) {
         gm_sq_tiles(B, F, W, K, M, vec, mode, beta, c1, c2, newrow, t0, t1, false);
     });
     if (!shared) gm_sq_core<5, 2>(G, lvec, lused, W, K, M, mode, beta, c1, c2, newrow, 0, Kp, tid, nthr);
@@ -882,7 +900,10 @@ DEV void gm_rank1(const Blk &B, const GmWork &W, int M, double *scr, FA fa, FB f
 }
 
 // re-estimate slot jj, MainEff.c:553-596
-DEVNI void gm_reestimate(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScalars &S, int jj, double newA)
+// `defer` (all four actions): leave the K-space half -- the Gram-row sweep with the S_in / Q_in update -- in S.pend
+// instead of running it (gm_flush_pending runs it later, or nobody does: gm_inner).  The vector stays in W.v2 (W.vb for
+// a run of adds), which nothing between here and the flush writes.
+DEVNI void gm_reestimate(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScalars &S, int jj, double newA, bool defer)
 {
     const int M = S.M, ld = W.ld;
     PAR(i, M) W.v2[i] = W.Sig[(size_t)jj * ld + i];
@@ -897,7 +918,8 @@ DEVNI void gm_reestimate(const Blk &B, const FoldDev &F, const GmWork &W, int K,
     { PH_BEGIN();
     gm_rank1(B, W, M, B.pool, [&](int j) { return -(kappa * W.v2[j]); }, [&](int i) { return W.v2[i]; });
     PH_END(PH_RANK1); }
-    gm_sq_update(B, F, W, K, M, W.v2, 0, S.beta, kappa, mujj, -1, S);
+    if (defer) { S.pend.kind = 1; S.pend.M = M; S.pend.beta = S.beta; S.pend.c1 = kappa; S.pend.c2 = mujj; }
+    else gm_sq_update(B, F, W, K, M, W.v2, 0, S.beta, kappa, mujj, -1, S);
 }
 
 // Gram row of feature u = the reference's BASIS_PHI row for that basis (MainEff.c:1608-1630):
@@ -1097,7 +1119,7 @@ DEV void gm_sigma_matvec(const Blk &B, const GmWork &W, int M, const double *v, 
 }
 
 // add feature nu, MainEff.c:1585-1723 + :613-627
-DEVNI void gm_add(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScalars &S, int nu, int rid, double newA)
+DEVNI void gm_add(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScalars &S, int nu, int rid, double newA, bool defer)
 {
     const int M = S.M, ld = W.ld;
     const double beta = S.beta;
@@ -1134,7 +1156,8 @@ DEVNI void gm_add(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScal
         if (B.tid == 0) W.Gc[(size_t)M * ld + M] = G[(size_t)rid * K + nu];
     }
 #endif
-    gm_sq_update(B, F, W, K, M, W.v2, 1, beta, sii, mui, rid, S);
+    if (defer) { S.pend.kind = 2; S.pend.M = M; S.pend.beta = beta; S.pend.c1 = sii; S.pend.c2 = mui; S.pend.row = rid; }
+    else gm_sq_update(B, F, W, K, M, W.v2, 1, beta, sii, mui, rid, S);
     GM_TRACE("    add nu=%d newA=%.15g sii=%.15g mui=%.15g tp0=%.15g tmp0=%.15g Sin=%.15g Qin=%.15g mu0=%.15g\n", nu, newA, sii, mui, W.v2[0], W.v1[0], W.Sin[nu], W.Qin[nu], W.mu[0]);
     S.M = M + 1;
 }
@@ -1305,9 +1328,10 @@ DEV void gm_sq_batch_range(const Blk &B, const FoldDev &F, const GmWork &W, int 
 // whoever runs it), the odd last feature by the owner
 DEVNI void gm_sq_batch_all(const Blk &B, const FoldDev &F, const GmWork &W, int K, int M0, int T, double beta, GmScalars &S)
 {
+    CNT(c.sum_m_swept += M0 + T);                               // one sweep of the final active set's rows for the whole run
     const int Kp = K & ~1;
     const int n_tiles = (Kp + SQ_FT - 1) / SQ_FT;
-    const bool shared = M0 + T >= 96 && job_share(B, S, JOB_SQB, M0, n_tiles, beta, T, -1, 0.0, 0.0, [&](int t0, int t1) {
+    const bool shared = M0 + T >= 96 && job_share(B, S, JOB_SQB, M0, n_tiles, beta, T, -1, -1, 0.0, 0.0, [&](int t0, int t1) {
         gm_sq_batch_range(B, F, W, K, M0, T, beta, t0 * SQ_FT, t1 * SQ_FT < Kp ? t1 * SQ_FT : Kp);
     });
     if (!shared) gm_sq_batch_range(B, F, W, K, M0, T, beta, 0, Kp);
@@ -1331,7 +1355,7 @@ DEVNI void gm_sq_batch_all(const Blk &B, const FoldDev &F, const GmWork &W, int 
 // M-space part needs in between are S_in / Q_in of the run's own features (sii, mui of the later adds):
 // those T values are tracked on the side with the same arithmetic (one lane per feature, rows in order).
 // W.rowid[M0 .. M0+T) must already hold the Gram row ids of the run's features.
-DEVNI void gm_add_batch(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScalars &S, const int *nus, int T)
+DEVNI void gm_add_batch(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScalars &S, const int *nus, int T, bool defer)
 {
     const int M0 = S.M, ld = W.ld, ldv = W.cap + 2, Mt = M0 + T;
     const double beta = S.beta;
@@ -1398,16 +1422,32 @@ DEVNI void gm_add_batch(const Blk &B, const FoldDev &F, const GmWork &W, int K, 
         if (S.gc_ok) PAR(j, M + 1) W.Gc[(size_t)j * ld + M] = gb[(size_t)t * Mt + j];   // the new slot's column of the Gram block cache
         blk_sync(B);
     }
-    PH_BEGIN();
-    gm_sq_batch_all(B, F, W, K, M0, T, beta, S);
-    PH_END(PH_KSWEEP);
+    if (defer) { S.pend.kind = 4; S.pend.M = M0; S.pend.T = T; S.pend.beta = beta; }
+    else {
+        PH_BEGIN();
+        gm_sq_batch_all(B, F, W, K, M0, T, beta, S);
+        PH_END(PH_KSWEEP);
+    }
     S.M = M0 + T;
 }
 #endif
 
+// the K-space half a block's last unit left in S.pend (gm_inner)
+DEV void gm_flush_pending(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScalars &S)
+{
+    const GmScalars::Pending p = S.pend;
+    S.pend.kind = 0;
+    if (p.kind == 1) gm_sq_update(B, F, W, K, p.M, W.v2, 0, p.beta, p.c1, p.c2, -1, S);
+    else if (p.kind == 2) gm_sq_update(B, F, W, K, p.M, W.v2, 1, p.beta, p.c1, p.c2, p.row, S);
+    else if (p.kind == 3) gm_sq_update(B, F, W, K, p.M, W.v2, 2, p.beta, p.c1, p.c2, -1, S, p.jj, p.row);
+#ifndef PAREBEN_HOST_EMUL
+    else if (p.kind == 4) { PH_BEGIN(); gm_sq_batch_all(B, F, W, K, p.M, p.T, p.beta, S); PH_END(PH_KSWEEP); }
+#endif
+}
+
 // delete slot jj, MainEff.c:1725-1822 + :640-651.  `nu` is the feature the action named; it
 // differs from used[jj] only on the reference's stale-slot path.
-DEVNI void gm_delete(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScalars &S, int jj, int nu)
+DEVNI void gm_delete(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScalars &S, int jj, int nu, bool defer)
 {
     const int M = S.M, ld = W.ld, last = M - 1;
     PAR(i, M) W.v2[i] = W.Sig[(size_t)jj * ld + i];
@@ -1416,7 +1456,9 @@ DEVNI void gm_delete(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmS
     const int mujj = (int)W.mu[jj];                           // Q2: int truncation
     const int gone = W.used[jj];
     const int gone_row = W.rowid[jj];
-    gm_sq_update(B, F, W, K, M, W.v2, 2, S.beta, sjj, (double)mujj, -1, S);
+    // the sweep runs over the rows as they are BEFORE the slot shuffle below; held back, it is told which slot was freed
+    if (defer) { S.pend.kind = 3; S.pend.M = M; S.pend.beta = S.beta; S.pend.c1 = sjj; S.pend.c2 = (double)mujj; S.pend.jj = jj; S.pend.row = gone_row; }
+    else gm_sq_update(B, F, W, K, M, W.v2, 2, S.beta, sjj, (double)mujj, -1, S);
     PAR(i, M) W.mu[i] = W.mu[i] - mujj * W.v2[i] / sjj;
     gm_rank1(B, W, M, B.pool, [&](int j) { return -W.v2[j]; }, [&](int i) { return W.v2[i] / sjj; });
     blk_sync(B);
@@ -1883,6 +1925,7 @@ DEV int gm_inner(const Blk &B, const FoldDev &F, const GmWork &W, int K, double 
 {
     const int N = F.N, ld = W.ld;
     const bool first = iter <= 1;
+    const bool defer_ok = S.defer;                            // PAREBEN_DEFER=0 (A/B runs): every sweep at its action
     if (first) {                                              // :1003-1090, Q1
         S.M = 1;
         if (!S.v.epis) S.beta = 1 / (varY * 0.01 + 1e-10);
@@ -1952,6 +1995,8 @@ DEV int gm_inner(const Blk &B, const FoldDev &F, const GmWork &W, int K, double 
         }
         if (!worthwhile) sel = ACT_TERM;
         PH_END(PH_DML);
+        bool any_upd = false;
+        S.pend.kind = 0;
         unsigned long long *const tr = gm_trace_rec(S);
         if (tr) gm_trace_decision(B, W, K, S, tr, iter, i_iter, nu, best, worthwhile, n_todo);
         if (worthwhile) {
@@ -1979,17 +2024,13 @@ DEV int gm_inner(const Blk &B, const FoldDev &F, const GmWork &W, int K, double 
                         }
                         if (!ok) { S.status |= ST_OVERFLOW | ST_ABORT; return 1; }
                         CNT(c.n_add += T; c.sum_m_action += (int64_t)T * S.M + (int64_t)T * (T - 1) / 2);
-                        gm_add_batch(B, F, W, K, S, W.todo + u, T);
+                        gm_add_batch(B, F, W, K, S, W.todo + u, T, defer_ok && u + T == n_todo);
                         if (S.M > W.cap_flag) S.status |= ST_OVERFLOW;   // past the reference's basisMax (MainEff.c:605-611): flagged, not stopped
                         u += T - 1;
                         nu = W.todo[u];
                         sel = ACT_ADD;
+                        any_upd = true;
                         blk_sync(B);
-                        { PH_BEGIN();
-                        gm_refresh_out(B, W, K);
-                        PAR(i, S.M) W.gam[i] = 1 - W.A[i] * W.Sig[(size_t)i * ld + i];
-                        blk_sync(B);
-                        PH_END(PH_REFRESH); }
                         CNT(if (S.M > c.m_max) c.m_max = S.M);
                         continue;
                     }
@@ -2007,36 +2048,44 @@ DEV int gm_inner(const Blk &B, const FoldDev &F, const GmWork &W, int K, double 
                 if (sel == ACT_REEST && fabs(log(newA) - log(W.A[jj])) <= S.v.reest_tol && any_del == 0)
                     sel = ACT_TERM;
                 blk_sync(B);
+                const bool defer = defer_ok && u == n_todo - 1;
                 bool upd = false;
                 if (sel == ACT_REEST) {
                     CNT(c.n_reest++; c.sum_m_action += S.M);
-                    gm_reestimate(B, F, W, K, S, jj, newA);
+                    gm_reestimate(B, F, W, K, S, jj, newA, defer);
                     upd = true;
                 } else if (sel == ACT_ADD) {
                     if (S.M + 1 > W.cap) { S.status |= ST_OVERFLOW | ST_ABORT; return 1; }
                     const int rid = gm_row(B, F, W, K, nu);
                     if (rid < 0) { S.status |= ST_OVERFLOW | ST_ABORT; return 1; }
                     CNT(c.n_add++; c.sum_m_action += S.M);
-                    gm_add(B, F, W, K, S, nu, rid, newA);
+                    gm_add(B, F, W, K, S, nu, rid, newA, defer);
                     if (S.M > W.cap_flag) S.status |= ST_OVERFLOW;
                     upd = true;
                 } else if (sel == ACT_DEL) {
                     CNT(c.n_del++; c.sum_m_action += S.M);
-                    gm_delete(B, F, W, K, S, jj, nu);
+                    gm_delete(B, F, W, K, S, jj, nu, defer);
                     upd = true;
                 }
                 if (upd) {
+                    any_upd = true;
                     blk_sync(B);
-                    { PH_BEGIN();
-                    gm_refresh_out(B, W, K);
-                    PAR(i, S.M) W.gam[i] = 1 - W.A[i] * W.Sig[(size_t)i * ld + i];
-                    blk_sync(B);
-                    PH_END(PH_REFRESH); }
                     CNT(if (S.M > c.m_max) c.m_max = S.M);
                 }
             }
+            if (any_upd) {                                    // gamma of the block's final model (:664-671; only the last refresh of a block is ever read)
+                PAR(i, S.M) W.gam[i] = 1 - W.A[i] * W.Sig[(size_t)i * ld + i];
+                blk_sync(B);
+            }
             PH_END(PH_ACTION);
         }
+        // The reference refreshes S_out / Q_out after every action (:664-671), but nothing reads them before the next dML
+        // pass, and S_in / Q_in between two actions only through the add of a later unit of the same block.  So the K-space
+        // half of a block's LAST unit waits (S.pend) until it is known whether the noise update below ends in a full-stat
+        // pass: that pass recomputes S_in / Q_in for every feature from Sigma and mu, and the sweep -- M Gram rows of K
+        // entries -- would be dead work (two of three inner iterations of BASELINE config 2 end that way).  Otherwise the
+        // sweep runs now, with the operands of its action, and S_out / Q_out are refreshed once.  Same values either way.
+        bool fs_done = false;
         if (sel == ACT_TERM || i_iter <= 10 || i_iter % 5 == 0 || n_todo >= 2) {   // :685-729
             const int M = S.M;
             PH_BEGIN();
@@ -2070,9 +2119,11 @@ DEV int gm_inner(const Blk &B, const FoldDev &F, const GmWork &W, int K, double 
             PH_END(PH_NOISE);
             if (fabs(dlb) > 1e-6) {
                 if (gm_final_update(B, F, W, K, S)) { S.status |= ST_CHOLESKY | ST_ABORT; return 1; }
-                if (sel != ACT_TERM) gm_fullstat(B, F, W, K, S, false);
+                if (sel != ACT_TERM) { S.pend.kind = 0; gm_fullstat(B, F, W, K, S, false); fs_done = true; }
             }
         }
+        if (S.pend.kind) { PH_BEGIN(); gm_flush_pending(B, F, W, K, S); PH_END(PH_ACTION); }
+        if (any_upd && !fs_done) { PH_BEGIN(); gm_refresh_out(B, W, K); PH_END(PH_REFRESH); }
         GM_TRACE("  it %d.%d M=%d sel=%d ntodo=%d beta=%.15g mu0=%.15g A0=%.15g gam0=%.15g\n", iter, i_iter, S.M, sel, n_todo, S.beta, W.mu[0], W.A[0], W.gam[0]);
         if (tr) gm_trace_state(B, W, K, S, tr, sel);
         if (sel == ACT_TERM && ini_removed) last_it = 1;

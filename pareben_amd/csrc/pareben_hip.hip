@@ -363,6 +363,7 @@ struct CvParams {
     int *active;
     int early;                         // share from the start (few fits per workgroup)
     int heavy_m;                       // active-set size from which a fit shares its phases from the start
+    int defer;                         // hold back the sweep of a block's last unit (gm_inner); PAREBEN_DEFER=0: off
     GmVariant v;
 };
 
@@ -394,7 +395,7 @@ __device__ inline void store_counters(long long *dst, const FitCounters &c)
 {
     dst[0] = c.n_outer; dst[1] = c.n_inner; dst[2] = c.n_add; dst[3] = c.n_del; dst[4] = c.n_reest;
     dst[5] = c.n_fullstat; dst[6] = c.sum_m_action; dst[7] = c.sum_m_full; dst[8] = c.sum_m2_full;
-    dst[9] = c.m_final; dst[10] = c.m_max; dst[11] = c.status; dst[12] = c.mfma_tiles;
+    dst[9] = c.m_final; dst[10] = c.m_max; dst[11] = c.status; dst[12] = c.mfma_tiles; dst[13] = c.sum_m_swept;
 }
 
 // A workgroup that found the work queue empty helps the fits still running: it scans the job board (64
@@ -451,7 +452,7 @@ __device__ void fs_help_loop(const Blk &B, const FsShare &sh, int K, bool until_
         __syncthreads();
         FsJob *job = sh.jobs + owner;
         const int M = AT_LOAD(&job->M), fold = AT_LOAD(&job->fold), n_tiles = AT_LOAD(&job->n_tiles);
-        const int kind = AT_LOAD(&job->kind), mode = AT_LOAD(&job->mode), rid = AT_LOAD(&job->rid);
+        const int kind = AT_LOAD(&job->kind), mode = AT_LOAD(&job->mode), rid = AT_LOAD(&job->rid), aux = AT_LOAD(&job->pad);
         const double beta = __hip_atomic_load(&job->beta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const double c1 = __hip_atomic_load(&job->c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const double c2 = __hip_atomic_load(&job->c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -462,7 +463,8 @@ __device__ void fs_help_loop(const Blk &B, const FsShare &sh, int K, bool until_
             const int Kp = K & ~1;
             gm_sq_batch_range(B, Fo, Wo, K, M, mode, beta, first * SQ_FT, last * SQ_FT < Kp ? last * SQ_FT : Kp);
         } else if (kind == JOB_SQ)
-            gm_sq_tiles(B, Fo, Wo, K, M, Wo.v2, mode, beta, c1, c2, rid >= 0 ? Fo.G + (size_t)rid * K : nullptr, first, last, true);
+            gm_sq_tiles(B, Fo, Wo, K, M, Wo.v2, mode, beta, c1, c2, (mode == 1 && rid >= 0) ? Fo.G + (size_t)rid * K : nullptr, first, last, true,
+                        mode == 2 ? aux : -1, mode == 2 ? rid : -1);     // a held-back delete: the freed slot and its Gram row (gm_sq_stage)
         else
             gm_fullstat_features(B, Fo, Wo, K, M, beta, first, last);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // every wave drains its S_in / Q_in stores
@@ -506,6 +508,7 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_EU) void gm_cv_kernel(Cv
         S.v = P.v;
         S.share = &sh;
         S.fold = f;
+        S.defer = P.defer;
 #ifdef PAREBEN_PHASE_TIMERS
         if (threadIdx.x < PH_N) s_ph[threadIdx.x] = 0;
         __syncthreads();
@@ -545,7 +548,10 @@ struct BmCvParams {
     int pool_n;            // doubles of the dynamic LDS pool this launch was given (two 256-thread workgroups per CU: half the CU's LDS each)
 };
 
-__global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_EU) void bm_cv_kernel(BmCvParams P)
+#ifndef BM_WAVES_PER_EU
+#define BM_WAVES_PER_EU FIT_WAVES_PER_EU
+#endif
+__global__ __launch_bounds__(FIT_THREADS, BM_WAVES_PER_EU) void bm_cv_kernel(BmCvParams P)
 {
     __shared__ int s_unit;
     __shared__ FitCounters s_cnt;
@@ -603,6 +609,7 @@ struct FitParams {
     FsJob *jobs; int *active; int *queue; const FoldDev *folds; size_t ws_stride;
     unsigned long long *trace; long long trace_cap;    // decision trace (pareben_set_trace); null = off
     double *outer_log;                                 // verbose > 2: 3 doubles per outer iteration; null = off
+    int defer;
 };
 
 // single Gaussian fit with the reference's .C outputs: elasticNetLinearNeMainEff.c:199-227 (Beta K x 4:
@@ -638,7 +645,7 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_EU) void gm_fit_kernel(F
     S.ph = s_ph;
     S.v = P.v;
     if (P.jobs) { S.share = &sh; S.fold = 0; }
-    S.trace = P.trace; S.trace_cap = P.trace_cap; S.outer_log = P.outer_log;
+    S.trace = P.trace; S.trace_cap = P.trace_cap; S.outer_log = P.outer_log; S.defer = P.defer;
     gm_fit(B, P.F, W, K, P.lambda, P.alpha, S);
     if (threadIdx.x == 0 && P.active) AT_ADD(P.active, -1);        // the helpers may go (every path of the owner gets here)
     const int M = S.M, ld = W.ld;
@@ -1064,12 +1071,14 @@ static int run_enqueue(pareben_ctx *c, int n_cells, const double *alpha, const d
 
     int occ = 1;
     const bool binom = c->prior == PAREBEN_PRIOR_BINOMIAL;
-    // Binomial fits are chains of small dependent steps (Newton iterations with an M x M inverse, line searches, barriers:
-    // the matrix pipes of a CU are busy under a tenth of the time with one fit on it), so a CU runs TWO fits at once:
-    // 256-thread workgroups, each with half of the CU's LDS; the register budget per wave is unchanged (one wave per SIMD
-    // and workgroup).  PAREBEN_BM_THREADS=512 brings the one-fit-per-CU launch back (A/B runs).
-    int bm_threads = 256, bm_pool = BM_POOL_DOUBLES_HALF;
-    if (const char *e = getenv("PAREBEN_BM_THREADS")) { if (atoi(e) == 512) { bm_threads = 512; bm_pool = LDS_POOL_DOUBLES; } }
+    // Binomial launch shape.  Default: one 512-thread workgroup per CU with the whole LDS pool.  Two fits per CU as
+    // 256-thread workgroups with half the pool each (PAREBEN_BM_THREADS=256) were measured on config 3 and are no faster
+    // (282 vs 273 ms per grid): every step of a fit takes twice as many trips with half the threads, so the two resident
+    // fits each run at half speed.  PAREBEN_BM_POOL=<doubles> sets the pool (a build with -DBM_WAVES_PER_EU=4 needs two
+    // 512-thread workgroups to fit in one CU's LDS).
+    int bm_threads = 512, bm_pool = LDS_POOL_DOUBLES;
+    if (const char *e = getenv("PAREBEN_BM_THREADS")) { if (atoi(e) == 256) { bm_threads = 256; bm_pool = BM_POOL_DOUBLES_HALF; } }
+    if (const char *e = getenv("PAREBEN_BM_POOL")) { const int v = atoi(e); if (v >= 4096 && v <= LDS_POOL_DOUBLES) bm_pool = v; }
     if (binom) {
         HIPCHK(hipFuncSetAttribute((const void *)bm_cv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_FOR(bm_pool)));
         HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, bm_cv_kernel, bm_threads, LDS_BYTES_FOR(bm_pool)));
@@ -1127,6 +1136,7 @@ static int run_enqueue(pareben_ctx *c, int n_cells, const double *alpha, const d
     // (measured on config-2 shares with 256 workgroups: 1250 fits 2.51 -> 2.27 s, 2500 fits 3.82 -> 3.55 s, 5000 fits 6.15 -> 6.37 s)
     P.early = (D.d_jobs && (share_mode == 2 || (share_mode < 0 && n_units <= 10 * blocks))) ? 1 : 0;
     { const char *hm = getenv("PAREBEN_HEAVY_M"); P.heavy_m = share_mode == 1 ? (1 << 30) : (hm ? atoi(hm) : 384); }
+    { const char *df = getenv("PAREBEN_DEFER"); P.defer = (df && atoi(df) == 0) ? 0 : 1; }
     if (binom) {
         BmCvParams Q;
         Q.folds = c->d_folds; Q.alpha = D.d_alpha; Q.lambda = D.d_lambda; Q.order = D.d_order; Q.queue = D.d_queue;
@@ -1519,6 +1529,7 @@ static int fit_one(int prior, int epis, const double *basis, const double *targe
         P.ws = c->d_ws; P.offK = c->L.offK; P.offSig = c->L.offSig; P.offM = c->L.offM; P.K = c->kfull; P.cap = c->cap; P.cap_flag = c->cap_ref;
         P.p = k; P.v = c->variant;
         P.trace = nullptr; P.trace_cap = 0; P.outer_log = nullptr;
+        { const char *df = getenv("PAREBEN_DEFER"); P.defer = (df && atoi(df) == 0) ? 0 : 1; }
         if (trace_host) {
             CK(dmalloc(&d_trace, (size_t)TR_NSLOT * (trace_cap + 1)));
             CK(hipMemset(d_trace, 0, sizeof(unsigned long long) * TR_NSLOT * (trace_cap + 1)));

@@ -44,8 +44,9 @@ struct FitCounters {
     int64_t n_outer, n_inner, n_add, n_del, n_reest, n_fullstat;
     int64_t sum_m_action, sum_m_full, sum_m2_full, m_final, m_max, status;
     int64_t mfma_tiles;   // 16 x 16 x 16 tile products (4 x v_mfma_f64_16x16x4_f64, 8192 flop) the fit's matrix-core passes execute
+    int64_t sum_m_swept;  // Gram rows the action sweeps actually read (sum_m_action minus the sweeps a following full-stat pass made unnecessary)
 };
-#define PAREBEN_NCOUNTERS 13
+#define PAREBEN_NCOUNTERS 14
 
 enum {
     ST_OVERFLOW = 1,      // active set exceeded the reference's basisMax (and, with ST_ABORT, the workspace capacity)

@@ -29,7 +29,7 @@ def cv_grid(BASIS, y, fold_id, n_folds, alpha, lam, prior="gaussian", epis=False
     fid = np.ascontiguousarray(fold_id, dtype=np.int32)
     a = np.ascontiguousarray(alpha, dtype=np.float64); l = np.ascontiguousarray(lam, dtype=np.float64)
     out = np.zeros((len(a), n_folds)); st = np.zeros((len(a), n_folds), dtype=np.int32)
-    cnt = np.zeros((len(a), n_folds, 13), dtype=np.int64)
+    cnt = np.zeros((len(a), n_folds, 14), dtype=np.int64)
     fn = (lib().emul_gf_cv_grid if epis else lib().emul_gm_cv_grid) if prior == "gaussian" else (lib().emul_bf_cv_grid if epis else lib().emul_bm_cv_grid)
     rc = fn(X.ctypes.data_as(dp), X.shape[0], X.shape[1], y.ctypes.data_as(dp), fid.ctypes.data_as(ip),
                                n_folds, a.ctypes.data_as(dp), l.ctypes.data_as(dp), len(a), out.ctypes.data_as(dp),

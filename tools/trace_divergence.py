@@ -45,6 +45,15 @@ def load_table(name):
 
 def training_set(name, cell, fold):
     from pareben_amd.grid import AssignToFolds, BuildGrid
+    if name.startswith("config4_"):                 # BASELINE config 4 (Epis = "yes") at k markers: grid and folds of the committed fixture
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from config4_table import load
+        k = int(name.split("_")[1])
+        X, y = load(k)
+        d = np.load(os.path.join(ROOT, "tests", "golden", "config4_k%d_cells.npz" % k))
+        i = int(np.nonzero(d["cells"] == cell)[0][0])
+        tr = d["fold_id"] != fold
+        return np.asfortranarray(X[tr]), np.ascontiguousarray(y[tr]), float(d["alpha"][i]), float(d["lam"][i])
     X, y = load_table(name)
     fid = AssignToFolds(X, 3, sample_kind="Rounding")
     alpha, lam = BuildGrid(X, y, 3)
@@ -55,6 +64,7 @@ def training_set(name, cell, fold):
 def run(name, cell, fold, backend, out):
     X, y, a, l = training_set(name, cell, fold)
     N, K = X.shape
+    epis = name.startswith("config4_")
     buf = np.zeros((MAXREC + 1) * NSLOT, dtype=np.uint64)
     dp = C.POINTER(C.c_double)
     bp = buf.ctypes.data_as(C.POINTER(C.c_uint64))
@@ -63,7 +73,9 @@ def run(name, cell, fold, backend, out):
         L = oracle_lib.lib()
         L.eben_set_trace.argtypes = [C.POINTER(C.c_uint64), C.c_int64]
         L.eben_set_trace(bp, MAXREC)
-        r = oracle_lib.fit_gaussian(X, y, l, a)
+        if epis:
+            oracle_lib.set_capacity_policy(True, 0)
+        r = oracle_lib.fit_gaussian(X, y, l, a, epis=epis)
         L.eben_set_trace(None, 0)
         info = dict(intercept=r["intercept"], residual=r["residual"], counters=r["counters"])
     elif backend == "emul":
@@ -73,7 +85,7 @@ def run(name, cell, fold, backend, out):
         L.emul_set_trace(bp, MAXREC)
         cap = L.emul_default_cap(K)
         o = np.zeros(3); used = np.zeros(cap + 1, dtype=np.int32); mu = np.zeros(cap + 1); sd = np.zeros(cap + 1)
-        cnt = np.zeros(13, dtype=np.int64)
+        cnt = np.zeros(14, dtype=np.int64)
         L.emul_gm_fit(X.ctypes.data_as(dp), y.ctypes.data_as(dp), N, K, C.c_double(l), C.c_double(a), o.ctypes.data_as(dp),
                       used.ctypes.data_as(C.POINTER(C.c_int32)), mu.ctypes.data_as(dp), sd.ctypes.data_as(dp),
                       cnt.ctypes.data_as(C.POINTER(C.c_int64)))
@@ -86,9 +98,9 @@ def run(name, cell, fold, backend, out):
         L = _lib.load()
         L.pareben_set_trace.argtypes = [C.POINTER(C.c_uint64), C.c_int64]
         L.pareben_set_trace(bp, MAXREC)
-        Beta = np.zeros((K, 4), order="F"); w = C.c_double(); ic = C.c_double(); rs = C.c_double()
-        cnt = np.zeros(13, dtype=np.int64)
-        rc = L.pareben_fit_gaussian(X.ctypes.data_as(dp), y.ctypes.data_as(dp), l, a, Beta.ctypes.data_as(dp), C.byref(w), C.byref(ic),
+        Beta = np.zeros((K * (K + 1) // 2, 5) if epis else (K, 4), order="F"); w = C.c_double(); ic = C.c_double(); rs = C.c_double()
+        cnt = np.zeros(14, dtype=np.int64)
+        rc = (L.pareben_fit_gaussian_epis if epis else L.pareben_fit_gaussian)(X.ctypes.data_as(dp), y.ctypes.data_as(dp), l, a, Beta.ctypes.data_as(dp), C.byref(w), C.byref(ic),
                                     N, K, 0, C.byref(rs), 0, cnt.ctypes.data_as(C.POINTER(C.c_int64)))
         L.pareben_set_trace(None, 0)
         assert rc == 0, L.pareben_last_error()
