@@ -141,18 +141,28 @@ int pareben_lambda_max_pairs(const double *basis, int n, int p, const double *ta
 /*
  * The same grid on n_gpu devices of one node from ONE host process (the caller is a single R session;
  * reference call site: the foreach over grid rows, R/CrossValidate.R:66-70, whose workers were separate R
- * processes): one host thread and context per device, BASIS / Target / fold ids replicated, the cells dealt
- * round-robin over the cost-sorted list, and the path's only exchange -- one grouped ncclAllGather (RCCL over
- * xGMI, ncclCommInitAll communicators) of the device-resident per-cell results, after which every GPU holds
- * the whole table and the host copies it from device 0.  n_gpu <= 0 uses every visible device.  Results are
- * bit-identical for any n_gpu (a fit's arithmetic does not depend on what else runs).  RCCL is bound at
- * run time: without librccl.so this entry returns PAREBEN_EUNSUPPORTED and everything else still works.
+ * processes): one host thread and context per device, BASIS / Target / fold ids replicated; the (cell, fold)
+ * units are not dealt out in advance -- every device's persistent fit kernel pulls from ONE cost-sorted queue
+ * whose head sits in pinned, coherent host memory (system-scope atomic), as foreach's workers took the next
+ * row -- and the path's only exchange is one grouped ncclAllGather (RCCL over xGMI; ncclCommInitAll
+ * communicators, created on first use for a GPU count and kept) of the per-device result tables, after which
+ * every GPU holds all of them and the host merges them from the first.  n_gpu <= 0 uses every visible device.
+ * Results are bit-identical for any n_gpu and any timing (a fit's arithmetic does not depend on what else
+ * runs or where).  With one GPU nothing is exchanged and RCCL is not touched; RCCL is bound at run time:
+ * without librccl.so a call with n_gpu > 1 returns PAREBEN_EUNSUPPORTED and everything else still works.
+ * The caller's current HIP device is restored on return.
  */
 int pareben_cv_grid_multi(const double *basis, int n, int p, const double *target,
                           const int32_t *fold_id, int n_folds,
                           const double *alpha, const double *lambda, int n_cells,
                           int epis, int prior, int n_gpu,
                           double *fold_err, int32_t *status, int64_t *counters);
+
+/* Communicators of pareben_cv_grid_multi are created on first use for a GPU count and kept; this frees them. */
+int pareben_multi_release(void);
+/* Last pareben_cv_grid_multi call: out[0] = ranks of the RCCL communicator (1 when one GPU ran and nothing was
+ * exchanged), out[1] / out[2] = units pulled from the shared queue by the busiest / idlest GPU, out[3] = GPUs. */
+int pareben_multi_last_stats(int64_t out[4]);
 
 /*
  * One fit on all rows, same argument tuple as the reference's .C entry

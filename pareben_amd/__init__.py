@@ -8,8 +8,8 @@ Public surface (mirrors the reference's R names):
 from .grid import BuildGrid, GetLambdaMax, AssignToFolds, summarise_cv
 from .cv import CrossValidate
 from .local import LocalSearch
-from ._lib import Context, cv_grid_multi, fit_gaussian, fit_binomial, ParebenError, load as load_library
+from ._lib import Context, cv_grid_multi, multi_last_stats, fit_gaussian, fit_binomial, ParebenError, load as load_library
 from .eben import EBelasticNet, pt
 
 __all__ = ["CrossValidate", "LocalSearch", "BuildGrid", "GetLambdaMax", "AssignToFolds", "summarise_cv",
-           "Context", "cv_grid_multi", "fit_gaussian", "fit_binomial", "EBelasticNet", "pt", "ParebenError", "load_library"]
+           "Context", "cv_grid_multi", "multi_last_stats", "fit_gaussian", "fit_binomial", "EBelasticNet", "pt", "ParebenError", "load_library"]

@@ -165,6 +165,14 @@ def cv_grid_multi(BASIS, Target, fold_id, n_folds, alpha, lam, prior="gaussian",
     return err, st, cnt
 
 
+def multi_last_stats():
+    """(ranks in the RCCL communicator | 1 when nothing was exchanged, units pulled by the busiest GPU, by the idlest, GPUs)
+    of the last cv_grid_multi call."""
+    out = np.zeros(4, dtype=np.int64)
+    _chk(load().pareben_multi_last_stats(_lp(out)), "pareben_multi_last_stats")
+    return tuple(int(v) for v in out)
+
+
 def fit_gaussian(BASIS, Target, lam, alpha, device=0, epis=False):
     """Mirror of the reference's .C("elasticNetLinearNeMainEff") / .C("elasticNetLinearNeEpisEff") tuples
     (EBEN_orig/R/EBelasticNet.Gaussian.R:16-51) -> dict(Beta K x 4 | K(K+1)/2 x 5, wald, intercept,

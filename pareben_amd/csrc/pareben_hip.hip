@@ -19,6 +19,7 @@
 #include <numeric>
 #include <string>
 #include <thread>
+#include <mutex>
 #include <dlfcn.h>
 #include <rccl/rccl.h>           // types and prototypes only: the library is bound at run time (rccl_load)
 
@@ -364,6 +365,7 @@ struct CvParams {
     int early;                         // share from the start (few fits per workgroup)
     int heavy_m;                       // active-set size from which a fit shares its phases from the start
     int defer;                         // hold back the sweep of a block's last unit (gm_inner); PAREBEN_DEFER=0: off
+    int queue_sys;                     // the queue head is shared by several GPUs (pinned host memory, pareben_cv_grid_multi)
     GmVariant v;
 };
 
@@ -494,7 +496,8 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_EU) void gm_cv_kernel(Cv
     for (int n_done = 0;; n_done++) {
         if (n_done > 0) fs_help_loop(B, sh, P.K, false);            // between fits: lend a hand to the long ones
         __syncthreads();
-        if (threadIdx.x == 0) s_unit = atomicAdd(P.queue, 1);
+        // one queue head per launch in HBM, or one for all GPUs of a multi-GPU call in pinned host memory (system scope)
+        if (threadIdx.x == 0) s_unit = P.queue_sys ? __hip_atomic_fetch_add(P.queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : atomicAdd(P.queue, 1);
         __syncthreads();
         const int q = s_unit;
         if (q >= P.n_units) break;                 // every wave of every workgroup reaches this
@@ -546,6 +549,7 @@ struct BmCvParams {
     int epis, bmax;        // epistasis: NeFull.c rule set on the expanded design, at most bmax bases per model
     long long *phase;      // [n_units x PH_N] diagnostic ticks, may be null
     int pool_n;            // doubles of the dynamic LDS pool this launch was given (two 256-thread workgroups per CU: half the CU's LDS each)
+    int queue_sys;         // see CvParams
 };
 
 #ifndef BM_WAVES_PER_EU
@@ -561,7 +565,8 @@ __global__ __launch_bounds__(FIT_THREADS, BM_WAVES_PER_EU) void bm_cv_kernel(BmC
     W.phi_div = P.epis; W.bmax = P.bmax;
     for (;;) {
         __syncthreads();
-        if (threadIdx.x == 0) s_unit = atomicAdd(P.queue, 1);
+        // one queue head per launch in HBM, or one for all GPUs of a multi-GPU call in pinned host memory (system scope)
+        if (threadIdx.x == 0) s_unit = P.queue_sys ? __hip_atomic_fetch_add(P.queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : atomicAdd(P.queue, 1);
         __syncthreads();
         const int q = s_unit;
         if (q >= P.n_units) break;
@@ -1039,7 +1044,10 @@ struct RunDev {
 
 // Enqueue one grid evaluation on the context's stream: parameter upload, per-fold preparation, the persistent fit
 // kernel.  Events ev[0..2] bracket preparation and fit.  Nothing is synchronised here.
-static int run_enqueue(pareben_ctx *c, int n_cells, const double *alpha, const double *lambda, bool want_counters, RunDev &D)
+// shared_queue: null = the launch has its own queue head; else the pinned-host head all GPUs of a multi-GPU call pull
+// from (zeroed by the caller) and n_sharers = how many launches share it
+static int run_enqueue(pareben_ctx *c, int n_cells, const double *alpha, const double *lambda, bool want_counters, RunDev &D,
+                       int *shared_queue = nullptr, int n_sharers = 1)
 {
     HIPCHK(hipSetDevice(c->device));
     const int nF = c->n_folds, n_units = n_cells * nF;
@@ -1108,6 +1116,7 @@ static int run_enqueue(pareben_ctx *c, int n_cells, const double *alpha, const d
     CK(hipMemcpyAsync(D.d_lambda, lambda, sizeof(double) * n_cells, hipMemcpyHostToDevice, c->stream));
     CK(hipMemcpyAsync(D.d_order, D.order.data(), sizeof(int) * n_units, hipMemcpyHostToDevice, c->stream));
     CK(hipMemsetAsync(D.d_queue, 0, sizeof(int), c->stream));
+    int *const queue = shared_queue ? shared_queue : D.d_queue;
     // PAREBEN_SHARE (A/B tests): 0 = no shared phases, 1 = in the tail only, 2 = from the start; unset = automatic
     const char *share_env = getenv("PAREBEN_SHARE");
     const int share_mode = share_env ? atoi(share_env) : -1;
@@ -1126,7 +1135,7 @@ static int run_enqueue(pareben_ctx *c, int n_cells, const double *alpha, const d
     CK(hipEventRecord(c->ev[1], c->stream));
 
     CvParams P;
-    P.folds = c->d_folds; P.alpha = D.d_alpha; P.lambda = D.d_lambda; P.order = D.d_order; P.queue = D.d_queue;
+    P.folds = c->d_folds; P.alpha = D.d_alpha; P.lambda = D.d_lambda; P.order = D.d_order; P.queue = queue; P.queue_sys = shared_queue ? 1 : 0;
     P.fold_err = D.d_err; P.status = D.d_status; P.counters = D.d_cnt; P.phase = D.d_phase; P.ws = c->d_ws;
     P.ws_stride = c->L.bytes; P.offK = c->L.offK; P.offSig = c->L.offSig; P.offM = c->L.offM;
     P.K = c->kfull; P.cap = c->cap; P.cap_flag = c->cap_ref; P.n_folds = nF; P.n_units = n_units; P.v = c->variant;
@@ -1134,12 +1143,12 @@ static int run_enqueue(pareben_ctx *c, int n_cells, const double *alpha, const d
     P.jobs = D.d_jobs; P.active = D.d_active;
     // with only a handful of fits per workgroup the longest fits decide the step time: share from the start
     // (measured on config-2 shares with 256 workgroups: 1250 fits 2.51 -> 2.27 s, 2500 fits 3.82 -> 3.55 s, 5000 fits 6.15 -> 6.37 s)
-    P.early = (D.d_jobs && (share_mode == 2 || (share_mode < 0 && n_units <= 10 * blocks))) ? 1 : 0;
+    P.early = (D.d_jobs && (share_mode == 2 || (share_mode < 0 && n_units / n_sharers <= 10 * blocks))) ? 1 : 0;
     { const char *hm = getenv("PAREBEN_HEAVY_M"); P.heavy_m = share_mode == 1 ? (1 << 30) : (hm ? atoi(hm) : 384); }
     { const char *df = getenv("PAREBEN_DEFER"); P.defer = (df && atoi(df) == 0) ? 0 : 1; }
     if (binom) {
         BmCvParams Q;
-        Q.folds = c->d_folds; Q.alpha = D.d_alpha; Q.lambda = D.d_lambda; Q.order = D.d_order; Q.queue = D.d_queue;
+        Q.folds = c->d_folds; Q.alpha = D.d_alpha; Q.lambda = D.d_lambda; Q.order = D.d_order; Q.queue = queue; Q.queue_sys = shared_queue ? 1 : 0;
         Q.fold_err = D.d_err; Q.status = D.d_status; Q.counters = D.d_cnt; Q.ws = c->d_ws; Q.L = c->BL;
         Q.K = c->kfull; Q.n_folds = nF; Q.n_units = n_units; Q.phase = D.d_phase;
         Q.epis = c->epis; Q.bmax = 2 * c->p; Q.pool_n = bm_pool;
@@ -1325,11 +1334,16 @@ extern "C" int pareben_lambda_max_pairs(const double *basis, int n, int p, const
 }
 
 // ------------------------------------------------------------------------------------------
-// Multi-GPU grid evaluation behind the C ABI: ONE host process (the caller is a single R
-// session), one host thread + context per device, cells dealt round-robin over the cost-sorted list, and the
-// path's only exchange -- one grouped ncclAllGather (RCCL over xGMI) of the device-resident per-cell results,
-// after which every GPU holds the whole table and the host reads it from the first.
-// RCCL is bound at run time (dlopen), so the library loads and the single-GPU entries work without it.
+// Multi-GPU grid evaluation behind the C ABI (SURVEY.md 8(b)/(e), R/CrossValidate.R:66-70): ONE host process (the caller is
+// a single R session), one host thread + context per device.  The (cell, fold) units are NOT dealt out in advance: every
+// GPU's persistent fit kernel pulls from ONE cost-sorted queue whose head is an int in pinned, coherent host memory
+// (system-scope atomic add), so a GPU that drew the heavy fits simply takes fewer units.  Which GPU computed a unit
+// never shows in its value (a fit's arithmetic depends on nothing outside the fit), so the table is bit-identical for any
+// GPU count and any timing.  The path's only exchange is one grouped ncclAllGather (RCCL over xGMI) of the per-GPU result
+// tables, after which every GPU holds every slice and the host merges them from the first (a unit's slot is valid on
+// exactly the GPU whose status word for it is not the poison value).
+// RCCL is bound at run time (dlopen, once per process) so the library loads and the single-GPU entries work without it;
+// communicators are created on first use for a given GPU count and kept (pareben_multi_release frees them).
 struct Rccl {
     void *h = nullptr;
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
@@ -1337,39 +1351,64 @@ struct Rccl {
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
 };
+static std::mutex g_multi_mu;                 // one multi-GPU call at a time per process (they would share every device anyway)
+static Rccl g_rccl;
+static std::vector<ncclComm_t> g_comms;       // communicators of the last GPU count used, device g = rank g
+static int64_t g_multi_stats[4] = {0, 0, 0, 0};   // last call: ranks in the communicator, units pulled by the busiest / idlest GPU, GPUs
+
 static int rccl_load(Rccl &R)
 {
+    if (R.h) return PAREBEN_OK;
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char *n : names) { R.h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (R.h) break; }
-    if (!R.h) return fail(PAREBEN_EUNSUPPORTED, "RCCL (librccl.so) not found: the multi-GPU entry needs it");
-    R.CommInitAll = (decltype(R.CommInitAll))dlsym(R.h, "ncclCommInitAll");
-    R.CommDestroy = (decltype(R.CommDestroy))dlsym(R.h, "ncclCommDestroy");
-    R.GroupStart = (decltype(R.GroupStart))dlsym(R.h, "ncclGroupStart");
-    R.GroupEnd = (decltype(R.GroupEnd))dlsym(R.h, "ncclGroupEnd");
-    R.AllGather = (decltype(R.AllGather))dlsym(R.h, "ncclAllGather");
-    R.GetErrorString = (decltype(R.GetErrorString))dlsym(R.h, "ncclGetErrorString");
-    if (!R.CommInitAll || !R.CommDestroy || !R.GroupStart || !R.GroupEnd || !R.AllGather || !R.GetErrorString)
+    void *h = nullptr;
+    for (const char *n : names) { h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (h) break; }
+    if (!h) return fail(PAREBEN_EUNSUPPORTED, "RCCL (librccl.so) not found: the multi-GPU entry needs it for more than one GPU");
+    R.CommInitAll = (decltype(R.CommInitAll))dlsym(h, "ncclCommInitAll");
+    R.CommDestroy = (decltype(R.CommDestroy))dlsym(h, "ncclCommDestroy");
+    R.GroupStart = (decltype(R.GroupStart))dlsym(h, "ncclGroupStart");
+    R.GroupEnd = (decltype(R.GroupEnd))dlsym(h, "ncclGroupEnd");
+    R.AllGather = (decltype(R.AllGather))dlsym(h, "ncclAllGather");
+    R.CommCount = (decltype(R.CommCount))dlsym(h, "ncclCommCount");
+    R.GetErrorString = (decltype(R.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!R.CommInitAll || !R.CommDestroy || !R.GroupStart || !R.GroupEnd || !R.AllGather || !R.CommCount || !R.GetErrorString) {
+        dlclose(h);
         return fail(PAREBEN_EUNSUPPORTED, "librccl.so lacks an expected symbol");
+    }
+    R.h = h;
     return PAREBEN_OK;
 }
 
-// one row per cell of the rank's shard: (global cell id, n_folds scores, n_folds status words as doubles);
-// rows past the shard carry id -1
-__global__ void pack_kernel(const double *__restrict__ ids, const double *__restrict__ err, const int *__restrict__ st,
-                            int n_mine, int per, int nF, double *__restrict__ out)
+static void multi_release_locked()
+{
+    if (g_rccl.h) for (ncclComm_t c : g_comms) if (c) g_rccl.CommDestroy(c);
+    g_comms.clear();
+}
+extern "C" int pareben_multi_release(void)
+{
+    std::lock_guard<std::mutex> lk(g_multi_mu);
+    int dev = 0;
+    const bool have = hipGetDevice(&dev) == hipSuccess;
+    multi_release_locked();
+    if (have) hipSetDevice(dev);
+    return PAREBEN_OK;
+}
+extern "C" int pareben_multi_last_stats(int64_t out[4])
+{
+    if (!out) return fail(PAREBEN_EINVAL, "bad argument");
+    for (int i = 0; i < 4; i++) out[i] = g_multi_stats[i];
+    return PAREBEN_OK;
+}
+
+// one row per cell of this GPU's table: n_folds scores, then n_folds status words as doubles (poison -1 = not mine)
+__global__ void pack_kernel(const double *__restrict__ err, const int *__restrict__ st, int n_cells, int nF, double *__restrict__ out)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= per) return;
-    double *row = out + (size_t)c * (2 * nF + 1);
-    if (c < n_mine) {
-        row[0] = ids[c];
-        for (int f = 0; f < nF; f++) { row[1 + f] = err[(size_t)c * nF + f]; row[1 + nF + f] = (double)st[(size_t)c * nF + f]; }
-    } else {
-        row[0] = -1.0;
-        for (int f = 0; f < 2 * nF; f++) row[1 + f] = 0.0;
-    }
+    if (c >= n_cells) return;
+    double *row = out + (size_t)c * (2 * nF);
+    for (int f = 0; f < nF; f++) { row[f] = err[(size_t)c * nF + f]; row[nF + f] = (double)st[(size_t)c * nF + f]; }
 }
 
 extern "C" int pareben_cv_grid_multi(const double *basis, int n, int p, const double *target,
@@ -1383,96 +1422,125 @@ extern "C" int pareben_cv_grid_multi(const double *basis, int n, int p, const do
     HIPCHK(hipGetDeviceCount(&ndev));
     if (n_gpu <= 0) n_gpu = ndev;
     if (n_gpu < 1 || n_gpu > ndev) return fail(PAREBEN_EINVAL, "n_gpu exceeds the visible devices");
-    if (n_gpu > n_cells) n_gpu = n_cells;
-    const int nF = n_folds, row = 2 * nF + 1;
-    const int per = (n_cells + n_gpu - 1) / n_gpu;
-    // shard: cost-sorted (small lambda first, then alpha), dealt round-robin -- the same split as pareben_amd.dist.shard_cells
-    std::vector<int> order(n_cells);
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-        if (lambda[a] != lambda[b]) return lambda[a] < lambda[b];
-        return alpha[a] < alpha[b];
-    });
+    // Test hook: PAREBEN_MULTI_DEVICES="0,0" runs that many ranks on the named devices (the same one may repeat) with the
+    // merge done on the host instead of RCCL, which refuses duplicate devices -- the N > 1 deal and merge on a one-GPU box.
+    std::vector<int> devs;
+    bool host_gather = false;
+    if (const char *e = getenv("PAREBEN_MULTI_DEVICES")) {
+        for (const char *q = e; *q;) { devs.push_back(atoi(q)); while (*q && *q != ',') q++; if (*q == ',') q++; }
+        for (int d : devs) if (d < 0 || d >= ndev) return fail(PAREBEN_EINVAL, "PAREBEN_MULTI_DEVICES names a device that is not visible");
+        if (!devs.empty()) { n_gpu = (int)devs.size(); host_gather = true; }
+    }
+    if (devs.empty()) { devs.resize(n_gpu); std::iota(devs.begin(), devs.end(), 0); }
+    std::lock_guard<std::mutex> lk(g_multi_mu);
+    int dev_on_entry = 0;
+    HIPCHK(hipGetDevice(&dev_on_entry));
+    struct Restore { int d; ~Restore() { hipSetDevice(d); } } restore{dev_on_entry};
+
+    const int nF = n_folds, row = 2 * nF, n_units = n_cells * nF;
+    if (n_gpu == 1) host_gather = true;                         // one GPU: nothing to exchange, RCCL is not touched
+    // communicators first (cached per GPU count), so that their creation never competes with the persistent fit kernels
+    if (!host_gather) {
+        int rc = rccl_load(g_rccl);
+        if (rc) return rc;
+        if ((int)g_comms.size() != n_gpu) {
+            multi_release_locked();
+            g_comms.assign(n_gpu, nullptr);
+            const ncclResult_t nr = g_rccl.CommInitAll(g_comms.data(), n_gpu, devs.data());
+            if (nr != ncclSuccess) { g_comms.clear(); std::string m = std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(nr); return fail(PAREBEN_EHIP, m.c_str()); }
+        }
+        int cnt = 0;
+        if (g_rccl.CommCount(g_comms[0], &cnt) != ncclSuccess || cnt != n_gpu) return fail(PAREBEN_EHIP, "RCCL communicator has the wrong size");
+        g_multi_stats[0] = cnt;
+    } else g_multi_stats[0] = 1;
+    g_multi_stats[3] = n_gpu;
+
+    // the one queue head all GPUs pull from: pinned, coherent host memory, visible to every device
+    int *queue = nullptr;
+    if (hipHostMalloc((void **)&queue, 64, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess)
+        return fail(PAREBEN_ENOMEM, "pinned queue head");
+    *queue = 0;
     struct Rank {
-        pareben_ctx *ctx = nullptr; RunDev D; std::vector<int> cells; std::vector<double> a, l, ids;
-        double *d_ids = nullptr, *d_send = nullptr, *d_recv = nullptr; int rc = 0; std::string err;
+        pareben_ctx *ctx = nullptr; RunDev D; double *d_send = nullptr, *d_recv = nullptr; int rc = 0; std::string err;
+        std::vector<double> tab; std::vector<int64_t> cnt;
     };
     std::vector<Rank> R(n_gpu);
-    for (int k = 0; k < n_cells; k++) R[k % n_gpu].cells.push_back(order[k]);
     auto work = [&](int g) {
         Rank &r = R[g];
         auto bail = [&](int code) { r.rc = code; r.err = pareben_last_error(); };
-        const int nm = (int)r.cells.size();
-        r.a.resize(nm); r.l.resize(nm); r.ids.resize(nm);
-        for (int k = 0; k < nm; k++) { r.a[k] = alpha[r.cells[k]]; r.l[k] = lambda[r.cells[k]]; r.ids[k] = (double)r.cells[k]; }
-        int rc = pareben_ctx_create(&r.ctx, g, basis, n, p, target, fold_id, n_folds, prior, epis, 0);
+        int rc = pareben_ctx_create(&r.ctx, devs[g], basis, n, p, target, fold_id, n_folds, prior, epis, 0);
         if (rc) return bail(rc);
-        rc = run_enqueue(r.ctx, nm, r.a.data(), r.l.data(), counters != nullptr, r.D);
+        rc = run_enqueue(r.ctx, n_cells, alpha, lambda, counters != nullptr, r.D, queue, n_gpu);
         if (rc) return bail(rc);
         hipStream_t s = r.ctx->stream;
-        if (dmalloc(&r.d_ids, (size_t)nm) != hipSuccess || dmalloc(&r.d_send, (size_t)per * row) != hipSuccess ||
-            dmalloc(&r.d_recv, (size_t)n_gpu * per * row) != hipSuccess) return bail(fail(PAREBEN_ENOMEM, "gather buffers"));
-        if (hipMemcpyAsync(r.d_ids, r.ids.data(), sizeof(double) * nm, hipMemcpyHostToDevice, s) != hipSuccess) return bail(fail(PAREBEN_EHIP, "ids upload"));
-        hipLaunchKernelGGL(pack_kernel, dim3((per + 127) / 128), dim3(128), 0, s, r.d_ids, r.D.d_err, r.D.d_status, nm, per, nF, r.d_send);
-        if (counters) {                                          // diagnostics only: straight to the host table, not part of the exchange
-            std::vector<int64_t> cl((size_t)nm * nF * PAREBEN_NCOUNTERS);
-            if (hipMemcpyAsync(cl.data(), r.D.d_cnt, sizeof(int64_t) * cl.size(), hipMemcpyDeviceToHost, s) != hipSuccess ||
-                hipStreamSynchronize(s) != hipSuccess) return bail(fail(PAREBEN_EHIP, "counter copy"));
-            for (int k = 0; k < nm; k++)
-                memcpy(counters + (size_t)r.cells[k] * nF * PAREBEN_NCOUNTERS, cl.data() + (size_t)k * nF * PAREBEN_NCOUNTERS, sizeof(int64_t) * nF * PAREBEN_NCOUNTERS);
+        if (dmalloc(&r.d_send, (size_t)n_cells * row) != hipSuccess ||
+            (!host_gather && dmalloc(&r.d_recv, (size_t)n_gpu * n_cells * row) != hipSuccess)) return bail(fail(PAREBEN_ENOMEM, "gather buffers"));
+        hipLaunchKernelGGL(pack_kernel, dim3((n_cells + 127) / 128), dim3(128), 0, s, r.D.d_err, r.D.d_status, n_cells, nF, r.d_send);
+        if (counters) {                                          // diagnostics only: straight to the host, not part of the exchange
+            r.cnt.resize((size_t)n_units * PAREBEN_NCOUNTERS);
+            if (hipMemcpyAsync(r.cnt.data(), r.D.d_cnt, sizeof(int64_t) * r.cnt.size(), hipMemcpyDeviceToHost, s) != hipSuccess) return bail(fail(PAREBEN_EHIP, "counter copy"));
+        }
+        if (host_gather) {
+            r.tab.resize((size_t)n_cells * row);
+            if (hipMemcpyAsync(r.tab.data(), r.d_send, sizeof(double) * r.tab.size(), hipMemcpyDeviceToHost, s) != hipSuccess) return bail(fail(PAREBEN_EHIP, "table copy"));
         }
         if (hipEventRecord(r.ctx->ev[3], s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return bail(fail(PAREBEN_EHIP, "fit launch", hipGetLastError()));
         run_timings(r.ctx);
     };
     std::vector<std::thread> th;
     for (int g = 0; g < n_gpu; g++) th.emplace_back(work, g);
-    // communicators come up while the GPUs fit
-    Rccl X;
-    std::vector<ncclComm_t> comms(n_gpu, nullptr);
-    std::vector<int> devs(n_gpu);
-    std::iota(devs.begin(), devs.end(), 0);
-    int rc = rccl_load(X);
-    ncclResult_t nr = ncclSuccess;
-    if (!rc) nr = X.CommInitAll(comms.data(), n_gpu, devs.data());
     for (auto &t : th) t.join();
     auto cleanup = [&]() {
         for (int g = 0; g < n_gpu; g++) {
-            if (R[g].ctx) hipSetDevice(g);
-            hipFree(R[g].d_ids); hipFree(R[g].d_send); hipFree(R[g].d_recv);
+            if (R[g].ctx) hipSetDevice(devs[g]);
+            hipFree(R[g].d_send); hipFree(R[g].d_recv);
             R[g].D.release();
-            if (comms[g]) X.CommDestroy(comms[g]);
             if (R[g].ctx) pareben_ctx_destroy(R[g].ctx);
         }
+        hipHostFree(queue);
     };
-    if (rc) { cleanup(); return rc; }
-    if (nr != ncclSuccess) { std::string m = std::string("ncclCommInitAll: ") + X.GetErrorString(nr); cleanup(); return fail(PAREBEN_EHIP, m.c_str()); }
     for (int g = 0; g < n_gpu; g++) if (R[g].rc) { const int code = R[g].rc; const std::string m = R[g].err; cleanup(); return fail(code, m.c_str()); }
-    // the path's one collective: every rank contributes its packed slice, every GPU ends with the whole table
-    nr = X.GroupStart();
-    for (int g = 0; g < n_gpu && nr == ncclSuccess; g++)
-        nr = X.AllGather(R[g].d_send, R[g].d_recv, (size_t)per * row, ncclDouble, comms[g], R[g].ctx->stream);
-    { const ncclResult_t ne = X.GroupEnd(); if (nr == ncclSuccess) nr = ne; }
-    if (nr != ncclSuccess) { std::string m = std::string("ncclAllGather: ") + X.GetErrorString(nr); cleanup(); return fail(PAREBEN_EHIP, m.c_str()); }
-    for (int g = 0; g < n_gpu; g++) {
-        hipSetDevice(g);
-        if (hipStreamSynchronize(R[g].ctx->stream) != hipSuccess) { cleanup(); return fail(PAREBEN_EHIP, "all-gather", hipGetLastError()); }
-    }
-    std::vector<double> tab((size_t)n_gpu * per * row);
-    hipSetDevice(0);
-    if (hipMemcpy(tab.data(), R[0].d_recv, sizeof(double) * tab.size(), hipMemcpyDeviceToHost) != hipSuccess) { cleanup(); return fail(PAREBEN_EHIP, "table copy", hipGetLastError()); }
-    int seen = 0;
-    for (size_t k = 0; k < (size_t)n_gpu * per; k++) {
-        const double *rw = tab.data() + k * row;
-        if (rw[0] < 0) continue;
-        const int cell = (int)rw[0];
-        for (int f = 0; f < nF; f++) {
-            fold_err[(size_t)cell * nF + f] = rw[1 + f];
-            if (status) status[(size_t)cell * nF + f] = (int32_t)rw[1 + nF + f];
+    std::vector<double> tab;                                     // [gpu][cell][2 nF]
+    if (host_gather) {
+        tab.resize((size_t)n_gpu * n_cells * row);
+        for (int g = 0; g < n_gpu; g++) memcpy(tab.data() + (size_t)g * n_cells * row, R[g].tab.data(), sizeof(double) * (size_t)n_cells * row);
+    } else {
+        // the path's one collective: every GPU contributes its table, every GPU ends with all of them
+        ncclResult_t nr = g_rccl.GroupStart();
+        for (int g = 0; g < n_gpu && nr == ncclSuccess; g++)
+            nr = g_rccl.AllGather(R[g].d_send, R[g].d_recv, (size_t)n_cells * row, ncclDouble, g_comms[g], R[g].ctx->stream);
+        { const ncclResult_t ne = g_rccl.GroupEnd(); if (nr == ncclSuccess) nr = ne; }
+        if (nr != ncclSuccess) { std::string m = std::string("ncclAllGather: ") + g_rccl.GetErrorString(nr); cleanup(); return fail(PAREBEN_EHIP, m.c_str()); }
+        for (int g = 0; g < n_gpu; g++) {
+            hipSetDevice(devs[g]);
+            if (hipStreamSynchronize(R[g].ctx->stream) != hipSuccess) { cleanup(); return fail(PAREBEN_EHIP, "all-gather", hipGetLastError()); }
         }
-        seen++;
+        tab.resize((size_t)n_gpu * n_cells * row);
+        hipSetDevice(devs[0]);
+        if (hipMemcpy(tab.data(), R[0].d_recv, sizeof(double) * tab.size(), hipMemcpyDeviceToHost) != hipSuccess) { cleanup(); return fail(PAREBEN_EHIP, "table copy", hipGetLastError()); }
     }
+    // merge: a unit belongs to the one GPU whose status word for it is not the poison value
+    int seen = 0, dup = 0;
+    std::vector<int64_t> pulled(n_gpu, 0);
+    for (int c = 0; c < n_cells; c++)
+        for (int f = 0; f < nF; f++) {
+            int owner = -1;
+            for (int g = 0; g < n_gpu; g++) {
+                const double *rw = tab.data() + ((size_t)g * n_cells + c) * row;
+                if (rw[nF + f] != -1.0) { if (owner >= 0) dup++; owner = g; }
+            }
+            if (owner < 0) continue;
+            const double *rw = tab.data() + ((size_t)owner * n_cells + c) * row;
+            fold_err[(size_t)c * nF + f] = rw[f];
+            if (status) status[(size_t)c * nF + f] = (int32_t)rw[nF + f];
+            if (counters) memcpy(counters + ((size_t)c * nF + f) * PAREBEN_NCOUNTERS, R[owner].cnt.data() + ((size_t)c * nF + f) * PAREBEN_NCOUNTERS, sizeof(int64_t) * PAREBEN_NCOUNTERS);
+            pulled[owner]++;
+            seen++;
+        }
+    g_multi_stats[1] = *std::max_element(pulled.begin(), pulled.end());
+    g_multi_stats[2] = *std::min_element(pulled.begin(), pulled.end());
     cleanup();
-    if (seen != n_cells) return fail(PAREBEN_EHIP, "all-gather returned an incomplete table");
+    if (seen != n_units || dup) return fail(PAREBEN_EHIP, "the merged table is incomplete or a unit was computed twice");
     return PAREBEN_OK;
 }
 

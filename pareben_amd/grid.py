@@ -39,11 +39,25 @@ def _pairs_host(X, centred):
     return best
 
 
-def GetLambdaMax(BASIS, Target, Epis="no", device=None):
+def _resolve_device(device):
+    """"auto": GPU 0 when the library sees a device, else the numpy path (a box without a GPU can build a grid, not fit it)."""
+    if device != "auto":
+        return device
+    try:
+        from . import _lib
+        return 0 if _lib.load().pareben_device_count() > 0 else None
+    except Exception:
+        return None
+
+
+def GetLambdaMax(BASIS, Target, Epis="no", device="auto"):
     """R/BuildGrid.R:5-32.  max(log 1.1, max_j x_j.response/|x_j|); with Epis="yes" also all
     pairs x_i*x_j, correlated with the centred but *un-normalised* target.
-    The O(n K^2) pairwise pass runs on GPU `device` (pareben_lambda_max_pairs) when one is given -- what
-    CrossValidate does -- and in numpy otherwise."""
+    The O(n K^2) pairwise pass runs on GPU `device` (pareben_lambda_max_pairs); device = "auto" (default) takes GPU 0
+    when there is one -- so a direct BuildGrid() and the grid inside CrossValidate() are the same numbers on a GPU box --
+    and the numpy pass otherwise; None forces numpy (the checker of the device pass).  The two passes sum in different
+    orders and can differ in the last bits: match grid cells by index, never by comparing lambda values."""
+    device = _resolve_device(device)
     X = _as_matrix(BASIS)
     yv = np.asarray(Target, dtype=np.float64).reshape(-1)
     lam = math.log(1.1)
@@ -66,7 +80,7 @@ def GetLambdaMax(BASIS, Target, Epis="no", device=None):
     return lam
 
 
-def BuildGrid(BASIS, Target, nFolds, Epis="no", nAlpha=20, nLambda=20, device=None):
+def BuildGrid(BASIS, Target, nFolds, Epis="no", nAlpha=20, nLambda=20, device="auto"):
     """R/BuildGrid.R:34-52.  Returns (alpha, lambda) arrays of the expanded grid, alpha fastest
     (``expand.grid(alpha = Alpha, lambda = Lambda)``).  nAlpha/nLambda default to the reference's
     hard-wired 20 x 20; other sizes are an extension: lambda keeps the

@@ -539,16 +539,18 @@ def test_lambda_max_pair_pass_on_device(golden, yeast):
         host = _pairs_host(np.asarray(X, dtype=np.float64), y - y.mean())
         dev = pareben_amd._lib.lambda_max_pairs(X, y)
         assert abs(dev - host) <= 1e-12 * abs(host), (dev, host)
-        a1, l1 = BuildGrid(X, y, 5, "yes")
+        a1, l1 = BuildGrid(X, y, 5, "yes", device=None)
         a2, l2 = BuildGrid(X, y, 5, "yes", device=0)
         assert np.array_equal(a1, a2) and np.allclose(l1, l2, rtol=1e-12, atol=0)
     assert pareben_amd._lib.lambda_max_pairs(golden.BASIS[:50, :1], golden.y[:50]) == -np.inf
 
 
-def test_multi_gpu_entry_through_rccl(golden):
-    """pareben_cv_grid_multi (one process, a host thread + context per device, ncclCommInitAll + one grouped
-    ncclAllGather of the device-resident results) on the devices this box has: the table that comes back through
-    RCCL is bit-identical to the single-context run, for Gaussian and binomial grids, with n_gpu given and defaulted."""
+def test_multi_gpu_entry(golden, monkeypatch):
+    """pareben_cv_grid_multi (one process, a host thread + context per device, every device's fit kernel pulling units
+    from ONE queue head in pinned host memory, one grouped ncclAllGather of the per-device tables): bit-identical to the
+    single-context run for Gaussian and binomial grids, with n_gpu given and defaulted.  With >= 2 devices visible the
+    n_gpu = 2 branch runs through RCCL and must report a 2-rank communicator; on a one-GPU box the N > 1 deal and merge
+    are exercised by two ranks on device 0 (PAREBEN_MULTI_DEVICES, host merge: RCCL refuses duplicate devices)."""
     X, y = golden.BASIS[:120, :90], golden.y[:120]
     fid = AssignToFolds(X, 3)
     alpha, lam = BuildGrid(X, y, 3)
@@ -559,6 +561,18 @@ def test_multi_gpu_entry_through_rccl(golden):
     for n_gpu in sorted({1, 0, min(n_dev, 2)}):
         E2, s2, c2 = pareben_amd.cv_grid_multi(X, y, fid, 3, alpha[sel], lam[sel], n_gpu=n_gpu)
         assert np.array_equal(E1, E2) and np.array_equal(s1, s2) and np.array_equal(c1, c2), n_gpu
+        ranks, most, least, gpus = pareben_amd.multi_last_stats()
+        want = n_dev if n_gpu == 0 else n_gpu
+        assert gpus == want and ranks == (want if want > 1 else 1) and most + least * (want - 1) <= 3 * len(sel) <= most * want
+    if n_dev >= 2:
+        pareben_amd.cv_grid_multi(X, y, fid, 3, alpha[sel], lam[sel], n_gpu=2)
+        assert pareben_amd.multi_last_stats()[0] == 2                # RCCL saw two ranks
+    monkeypatch.setenv("PAREBEN_MULTI_DEVICES", "0,0,0")             # three ranks on device 0: shared queue + merge
+    E5, s5, c5 = pareben_amd.cv_grid_multi(X, y, fid, 3, alpha[sel], lam[sel], n_gpu=1)
+    monkeypatch.delenv("PAREBEN_MULTI_DEVICES")
+    assert np.array_equal(E1, E5) and np.array_equal(s1, s5) and np.array_equal(c1, c5)
+    ranks, most, least, gpus = pareben_amd.multi_last_stats()
+    assert gpus == 3 and most + least <= 3 * len(sel) and most >= len(sel)
     out = pareben_amd.CrossValidate(X, y, nFolds=3, nGPU=0)
     ref = pareben_amd.CrossValidate(X, y, nFolds=3)
     assert out["lambda.optimal"] == ref["lambda.optimal"] and out["alpha.optimal"] == ref["alpha.optimal"]

@@ -18,13 +18,15 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")]
 import oracle_lib  # noqa: E402
 from config4_table import load  # noqa: E402
 
-CELLS = [40, 52, 55, 56, 59, 60, 69, 79, 100, 399]
+CELLS_BY_K = {300: [40, 52, 55, 56, 59, 60, 69, 79, 100, 399],      # k = 300: 45 150 columns, resident Gram matrices
+              600: [41, 50, 51, 56, 60, 64]}                          # k = 600: 180 300 columns, Gram rows on demand
 
 if __name__ == "__main__":
     src, out = sys.argv[1], sys.argv[2]
     threads = int(sys.argv[3]) if len(sys.argv) > 3 else 6
     d = np.load(src)
     k = int(d["k"])
+    CELLS = CELLS_BY_K[k]
     X, y = load(k)
     alpha, lam, fid = d["alpha"][CELLS], d["lam"][CELLS], d["fold_id"]
     oracle_lib.build()
