@@ -351,6 +351,8 @@ def main():
                        "aborted_fits": int(np.sum(st & 8 != 0)), "fits_past_reference_basisMax": int(np.sum(st & 1 != 0)),
                        "status_histogram": {str(int(k)): int(v) for k, v in zip(*np.unique(st, return_counts=True))},
                        "active_set_max": int(state["cnt"][..., 10].max()),
+                       "event_totals": {k: int(v) for k, v in zip(pareben_amd._lib.COUNTER_NAMES, state["cnt"].reshape(-1, state["cnt"].shape[-1]).sum(axis=0))
+                                        if k not in ("m_final", "m_max", "status")},
                        "launch": launch, "kernel_ms": tim},
             "roofline": roof,
         }

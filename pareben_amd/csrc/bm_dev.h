@@ -1,0 +1,427 @@
+// bm_dev.h -- the MI355X mapping of the phases of a binomial fit (bm_fit.h includes it after its prelude): the weighted
+// rows X' diag(w) Phi, the per-feature quadratic forms BP Sigma BP' and the Newton Hessian Phi' diag(w) Phi on the FP64
+// matrix cores, Phi mu with staged index pairs.  gfx950 only.
+#pragma once
+
+#if defined(PAREBEN_PHASE_TIMERS)
+#define PHX2_BEGIN(v) long long v = (B.tid == 0) ? (long long)wall_clock64() : 0
+#define PHX2_END(v, k) do { if (B.tid == 0) S.ph[k] += (long long)wall_clock64() - v; } while (0)
+#else
+#define PHX2_BEGIN(v) do {} while (0)
+#define PHX2_END(v, k) do {} while (0)
+#endif
+
+// pm[h] = sum_p Phi_p[h] * mu[p]
+DEVNI void bm_phi_mu(const Blk &B, const FoldDev &F, const BmWork &W, int M, const double *mu, double *out)
+{
+    const int N = F.N;
+    if (3 * M + 8 <= B.pool_n) {
+        // column ids, norms and coefficients staged in LDS first: the loop then has one coalesced design-column load per
+        // term and nothing behind a used[] -> rscale[] address chain; same expression, same order
+        double *lm = B.pool, *ls = B.pool + M;
+        int *lu = (int *)(B.pool + 2 * M);
+        blk_sync(B);
+        PAR(p, M) { lm[p] = mu[p]; if (p >= 1) { const int u = W.used[p - 1]; lu[p] = u; ls[p] = W.phi_div ? F.scale[u] : F.rscale[u]; } }
+        blk_sync(B);
+        const bool dv = W.phi_div != 0;
+        PAR(h, N) {
+            double a = 0;
+            a += 1.0 * lm[0];
+#pragma unroll 4
+            for (int p = 1; p < M; p++) {
+                const double x = F.X[(size_t)lu[p] * N + h];
+                a += (dv ? x / ls[p] : x * ls[p]) * lm[p];
+            }
+            out[h] = a;
+        }
+        blk_sync(B);
+        return;
+    }
+    bm_phi_mu_plain(B, F, W, M, mu, out);
+}
+
+// BP[i][p] = sum_h x_i[h] w[h] Phi_p[h] / |x_i| for all features i and model columns p < M;
+// also bb-style single columns through `only` (>= 0: only that column, written to W.bb).
+// One 16-feature tile of bm_weighted_rows on the matrix cores, NCT column tiles of the staged block (compile-time: no
+// guards around the matrix ops), EXT = the staged block carries the residual column (statistics wanted).
+template <int NCT, int EXT>
+DEV void bm_wr_tile(gptr_cd xa, lptr_d zb, lptr_d lw, int pitch, int Nu, int Nr, int l4, double (&out)[NCT][4], double &bbq_out)
+{
+    typedef double bd4 __attribute__((ext_vector_type(4)));
+    constexpr int RS = 8;
+    bd4 acc[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ct++) acc[ct] = bd4{0, 0, 0, 0};
+    double bbq = 0;
+    double an[RS];
+#pragma unroll
+    for (int u = 0; u < RS; u++) { const int h = 4 * u + l4; an[u] = xa[h < Nu ? h : Nu - 1]; }
+    double bn[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ct++) bn[ct] = zb[ct * 16 * pitch];
+    for (int h0 = 0; h0 < Nr; h0 += 4 * RS) {
+        double ac[RS];
+#pragma unroll
+        for (int u = 0; u < RS; u++) ac[u] = (h0 + 4 * u + l4 < Nu) ? an[u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < RS; u++) { const int h = h0 + 4 * RS + 4 * u + l4; an[u] = xa[h < Nu ? h : Nu - 1]; }
+#pragma unroll
+        for (int u = 0; u < RS; u++) {
+            const int hs = h0 + 4 * u;                             // wave-uniform
+            if (hs < Nr) {
+                double bc[NCT];
+#pragma unroll
+                for (int ct = 0; ct < NCT; ct++) bc[ct] = bn[ct];
+                const int hn = hs + 4 < Nr ? hs + 4 : hs;           // next step's B operands behind this step's matrix ops
+#pragma unroll
+                for (int ct = 0; ct < NCT; ct++) bn[ct] = zb[ct * 16 * pitch + hn];
+                const double a = ac[u];
+#pragma unroll
+                for (int ct = 0; ct < NCT; ct++) acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bc[ct], acc[ct], 0, 0, 0);
+                if (EXT) bbq += lw[hs + l4] * (a * a);
+            }
+        }
+    }
+#pragma unroll
+    for (int ct = 0; ct < NCT; ct++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) out[ct][r] = acc[ct][r];
+    bbq_out = bbq;
+}
+
+
+// want_stats (device build): also bb_i = x_i' diag(w) x_i -> W.bb[i] and ze_i = x_i' e -> W.aroot[i] (what the
+// full-stat pass needs per feature, NEmainEff.c:1745-1757), taken from the same pass over the design columns.
+// Returns 1 when it did (matrix-core path), 0 when the caller has to compute them.
+DEVNI int bm_weighted_rows(const Blk &B, const FoldDev &F, const BmWork &W, int K, int M, bool want_stats = false, long long *phx = nullptr)
+{
+    (void)phx;
+    const int N = F.N, ld = W.ld;
+    (void)want_stats;
+    // A small GEMM, X' (diag(w) Phi), on the FP64 matrix cores when the weighted model columns fit in LDS 16 at a
+    // time: Z_p = w .* Phi_p staged sample-contiguous with an odd pitch (zero-padded to whole 4-sample groups and
+    // whole 16-column tiles); a wave owns 16 features and all column tiles, walks the samples four at a time --
+    // A operand: lane l holds x[feature l & 15][sample h0 + (l >> 4)] straight from memory (the four lanes of a
+    // feature read consecutive samples; the line stays in L1 for the next three steps; eight steps' loads are issued
+    // together, a round ahead of the matrix ops that use them), B operand from LDS one step ahead -- and each
+    // accumulator tile is one fma chain over the samples in ascending order.  D register r of lane l is
+    // BP[feature (l >> 4) + 4 r][column l & 15]: rows of BP leave as 128-byte segments.
+    // want_stats: one more staged column, e: x_i'e falls out of the same products (column pn); x_i' diag(w) x_i is summed
+    // on the vector ALU from the operand already in registers and the weights staged behind the columns.
+    // Everything the loop branches on is put in SGPRs (arguments of a non-inlined function arrive in VGPRs: a guard on
+    // them becomes an exec mask around every matrix op) and LDS / global pointers carry their address space (a generic
+    // pointer makes every operand read a flat load followed by s_waitcnt vmcnt(0), which drains the prefetch).
+    {
+        typedef double bd4 __attribute__((ext_vector_type(4)));
+        constexpr int MAXCT = 4;
+        const int Nu = uni(N), Ku = uni(K), Mu = uni(M), ldu = uni(ld), ws = uni(want_stats ? 1 : 0);
+        const int Nr = (Nu + 3) & ~3, pitch = Nr + 1;
+        int pcm = ((uni(B.pool_n) - (ws ? Nr : 0)) / pitch) & ~15;
+        if (pcm > 16 * MAXCT) pcm = 16 * MAXCT;
+        if (pcm >= 16) {
+            const lptr_d Z = as_lds(uni_ptr(B.pool));          // [column][pitch]
+            const gptr_cd gX = as_global(uni_ptr(F.X)), gw = as_global(uni_ptr(W.w)), ge = as_global(uni_ptr(W.e));
+            const gptr_cd gsc = as_global(uni_ptr(F.scale));
+            const gptr_d gBP = as_global_rw(uni_ptr(W.BP)), gbb = as_global_rw(uni_ptr(W.bb)), gze = as_global_rw(uni_ptr(W.aroot));
+            const int lane = B.lane, wave = uni(B.wave), nwave = uni(B.nwave), tid = B.tid, nthr = uni(B.nthr);
+            const int l15 = lane & 15, l4 = lane >> 4;
+            for (int p0 = 0; p0 < Mu; p0 += 0) {
+                const int ext = (ws && p0 == 0) ? 1 : 0;
+                const int pn = Mu - p0 < pcm - ext ? Mu - p0 : pcm - ext;
+                const int pn16 = (pn + ext + 15) & ~15, nct = pn16 >> 4;
+                const lptr_d lw = Z + pcm * pitch;                     // the weights, zero beyond the last sample
+                blk_sync(B);
+                PHX_BEGIN(t_st);
+                for (int e = tid; e < pn16 * pitch; e += nthr) {
+                    const int pc = e / pitch, h = e - pc * pitch;
+                    double v = 0.0;
+                    if (h < Nu) {
+                        if (pc < pn) v = gw[h] * BM_PHI(p0 + pc, h);
+                        else if (ext && pc == pn) v = ge[h];
+                    }
+                    Z[e] = v;
+                }
+                if (ext) for (int h = tid; h < Nr; h += nthr) lw[h] = h < Nu ? gw[h] : 0.0;
+                blk_sync(B);
+                PHX_END(t_st, PH_HBUILD);
+                PHX_BEGIN(t_mm);
+                for (int ft = wave; ft * 16 < Ku; ft += nwave) {
+                    const int il = ft * 16 + l15;
+                    const gptr_cd xa = gX + (size_t)(il < Ku ? il : Ku - 1) * Nu;
+                    const lptr_d zb = Z + l15 * pitch + l4;
+                    double acc[MAXCT][4];
+                    double bbq = 0;
+#define BM_WR_CASE(n)                                                                                                   \
+                    case n: {                                                                                           \
+                        double o[n][4];                                                                                 \
+                        if (ext) bm_wr_tile<n, 1>(xa, zb, lw, pitch, Nu, Nr, l4, o, bbq);                               \
+                        else bm_wr_tile<n, 0>(xa, zb, lw, pitch, Nu, Nr, l4, o, bbq);                                   \
+                        _Pragma("unroll") for (int ct = 0; ct < n; ct++) _Pragma("unroll") for (int r = 0; r < 4; r++) acc[ct][r] = o[ct][r]; \
+                    } break;
+                    switch (nct) { BM_WR_CASE(1) BM_WR_CASE(2) BM_WR_CASE(3) default: BM_WR_CASE(4) }
+#undef BM_WR_CASE
+#pragma unroll
+                    for (int ct = 0; ct < MAXCT; ct++) {
+                        if (ct >= nct) continue;
+                        const int col = ct * 16 + l15;
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int i = ft * 16 + l4 + 4 * r;
+                            if (i < Ku) {
+                                if (col < pn) gBP[(size_t)i * ldu + p0 + col] = acc[ct][r] / gsc[i];
+                                else if (ext && col == pn) gze[i] = acc[ct][r];
+                            }
+                        }
+                    }
+                    if (ext) {                                 // the four sample groups of a feature sit 16 lanes apart
+                        bbq += __shfl_xor(bbq, 16, 64); bbq += __shfl_xor(bbq, 32, 64);
+                        if (l4 == 0 && il < Ku) gbb[il] = bbq;
+                    }
+                }
+                PHX_END(t_mm, PH_MATVEC);
+                p0 += pn;
+            }
+            blk_sync(B);
+            return 1;
+        }
+    }
+    // samples too many for a 16-column tile in LDS: vector-ALU version, as many columns as fit at a time
+    int pcn = B.pool_n / N;
+    if (pcn > M) pcn = M;
+    if (pcn >= 1) {
+        double *Z = B.pool;                                    // [pcn][N]
+        for (int p0 = 0; p0 < M; p0 += pcn) {
+            const int pn = M - p0 < pcn ? M - p0 : pcn;
+            blk_sync(B);
+            for (int e = B.tid; e < N * pn; e += B.nthr) {
+                const int pc = e / N, h = e - pc * N, p = p0 + pc;
+                Z[e] = W.w[h] * BM_PHI(p, h);
+            }
+            blk_sync(B);
+            for (int i = B.wave; i < K; i += B.nwave) {
+                const double *x = F.X + (size_t)i * N;
+                const double rsc = 1.0 / F.scale[i];
+                if (N <= 8 * 64) {                             // the design column lives in registers for all pn columns
+                    double xr[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) xr[k] = (B.lane + 64 * k < N) ? x[B.lane + 64 * k] : 0.0;
+                    for (int pc = 0; pc < pn; pc += 8) {       // eight columns per reduction tree (blk.h: wave_sum8)
+                        double a[8];
+#pragma unroll
+                        for (int c = 0; c < 8; c++) {
+                            const double *z = Z + (pc + c < pn ? pc + c : pn - 1) * N;
+                            double t = 0;
+#pragma unroll
+                            for (int k = 0; k < 8; k++) if (B.lane + 64 * k < N) t += xr[k] * z[B.lane + 64 * k];
+                            a[c] = t;
+                        }
+                        wave_sum8(a, B.lane);
+                        const int c = B.lane >> 3;
+                        if ((B.lane & 7) == 0 && pc + c < pn) W.BP[(size_t)i * ld + p0 + pc + c] = a[0] * rsc;
+                    }
+                } else {
+                    for (int pc = 0; pc < pn; pc++) {
+                        double a = 0;
+                        for (int h = B.lane; h < N; h += 64) a += x[h] * Z[pc * N + h];
+                        a = wave_sum(a);
+                        if (B.lane == 0) W.BP[(size_t)i * ld + p0 + pc] = a * rsc;
+                    }
+                }
+            }
+        }
+    } else {
+        for (int i = B.wave; i < K; i += B.nwave) {            // samples do not fit in LDS: columns from memory
+            const double *x = F.X + (size_t)i * N;
+            for (int p = 0; p < M; p++) {
+                double a = 0;
+                if (p == 0) { for (int h = B.lane; h < N; h += 64) a += x[h] * W.w[h]; }
+                else {
+                    const int u = W.used[p - 1];
+                    for (int h = B.lane; h < N; h += 64) a += (x[h] * W.w[h]) * bm_col(F, W, N, u, h);
+                }
+                a = wave_sum(a);
+                if (B.lane == 0) W.BP[(size_t)i * ld + p] = a / F.scale[i];
+            }
+        }
+    }
+    blk_sync(B);
+    return 0;
+}
+
+
+// S_in = bb_i / |x_i|^2 - BP_i' Sigma BP_i and Q_in = ze_i / |x_i| for every feature (NEmainEff.c:1732-1762), the
+// quadratic forms on the FP64 matrix cores: a wave owns 16 features; T = BP_tile * Sigma in 16 x 16 tiles (A operand:
+// lane l holds BP[feature l & 15][k0 + (l >> 4)], B operand Sigma[k0 + (l >> 4)][16 ct + (l & 15)], 64 columns of Sigma
+// per round), folded with BP on the fly: D register r of lane l is T[feature (l >> 4) + 4 r][column l & 15], multiplied
+// by the same BP entry and summed over the 16 lanes of a row group.
+DEVNI void bm_quad_features(const Blk &B, const FoldDev &F, const BmWork &W, int K, int M)
+{
+    typedef double bd4 __attribute__((ext_vector_type(4)));
+    const int ld = W.ld, l15 = B.lane & 15, l4 = B.lane >> 4;
+    const int nct = (M + 15) >> 4;
+    for (int ft = B.wave; ft * 16 < K; ft += B.nwave) {
+        const int ia = ft * 16 + l15;
+        const double *bpa = W.BP + (size_t)(ia < K ? ia : K - 1) * ld;
+        double q[4] = {0, 0, 0, 0};
+        for (int c0 = 0; c0 < nct; c0 += 4) {
+            bd4 acc[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[c] = bd4{0, 0, 0, 0};
+            for (int k0 = 0; k0 < M; k0 += 4) {
+                const int k = k0 + l4;
+                const double a = (k < M && ia < K) ? bpa[k] : 0.0;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const int col = (c0 + c) * 16 + l15;
+                    if (c0 + c < nct) {
+                        const double b = (k < M && col < M) ? W.Sig[(size_t)k * ld + col] : 0.0;
+                        acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[c], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int col = (c0 + c) * 16 + l15;
+                if (c0 + c < nct && col < M) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int i = ft * 16 + l4 + 4 * r;
+                        if (i < K) q[r] += acc[c][r] * W.BP[(size_t)i * ld + col];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            double v = q[r];
+            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+            const int i = ft * 16 + l4 + 4 * r;
+            if (l15 == 0 && i < K) {
+                const double sc = F.scale[i];
+                W.Sin[i] = W.bb[i] / (sc * sc) - v;
+                W.Qin[i] = W.aroot[i] / sc;
+            }
+        }
+    }
+    blk_sync(B);
+}
+
+// gradient entries 1 .. M-1 and the Hessian Phi' diag(w) Phi + diag(A) of one Newton step (NEmainEff.c:1890-1925)
+DEV void bm_grad_hessian(const Blk &B, const FoldDev &F, const BmWork &W, int M, int N)
+{
+    const int ld = W.ld;
+        for (int j = 1 + B.wave; j < M; j += B.nwave) {
+            double ga = 0, ha = 0;
+            for (int h = B.lane; h < N; h += 64) { const double ph = BM_PHI(j, h); ga += W.e[h] * ph; ha += W.w[h] * ph; }
+            ga = wave_sum(ga); ha = wave_sum(ha);
+            if (B.lane == 0) { W.g[j] = ga - W.A[j - 1] * W.mu[j]; W.H[j] = ha; W.H[(size_t)j * ld] = ha; }
+        }
+        if (M - 1 >= 8) {
+            // Phi' diag(w) Phi on the FP64 matrix cores: 16 x 16 tiles over the model columns 1 .. M-1, lower-triangle tile
+            // pairs dealt to the waves; A operand (phi_j w) and B operand phi_k straight from the design (lane l: column
+            // l & 15 of the tile, sample h0 + (l >> 4)), one fma chain over the samples in ascending order -- the product is
+            // associated as the reference does, (phi_j * w) * phi_k (:1911)
+            typedef double bd4 __attribute__((ext_vector_type(4)));
+            const int Mm = M - 1, nT = (Mm + 15) >> 4, l15 = B.lane & 15, l4 = B.lane >> 4;
+            const int Nr = (N + 3) & ~3;
+            for (int q = B.wave; q < nT * (nT + 1) / 2; q += B.nwave) {
+                int tj = (int)((sqrt(8.0 * q + 1.0) - 1.0) * 0.5);
+                while ((tj + 1) * (tj + 2) / 2 <= q) tj++;
+                while (tj * (tj + 1) / 2 > q) tj--;
+                const int tk = q - tj * (tj + 1) / 2;              // tk <= tj
+                const int ja = tj * 16 + l15, kb = tk * 16 + l15;  // model columns (0-based among 1 .. M-1) of this lane's operands
+                const int uj = W.used[ja < Mm ? ja : Mm - 1], uk = W.used[kb < Mm ? kb : Mm - 1];
+                const double *xj = F.X + (size_t)uj * N, *xk = F.X + (size_t)uk * N;
+                const double sj = W.phi_div ? F.scale[uj] : F.rscale[uj], sk = W.phi_div ? F.scale[uk] : F.rscale[uk];
+                const bool dv = W.phi_div != 0;
+                bd4 acc = bd4{0, 0, 0, 0};
+                constexpr int RS = 8;                              // eight steps' operand loads issued together, one round ahead
+                double xjn[RS], xkn[RS], wn[RS];
+#pragma unroll
+                for (int u = 0; u < RS; u++) { const int h = 4 * u + l4, hc = h < N ? h : N - 1; xjn[u] = xj[hc]; xkn[u] = xk[hc]; wn[u] = W.w[hc]; }
+                for (int h0 = 0; h0 < Nr; h0 += 4 * RS) {
+                    double xjc[RS], xkc[RS], wc[RS];
+#pragma unroll
+                    for (int u = 0; u < RS; u++) { xjc[u] = xjn[u]; xkc[u] = xkn[u]; wc[u] = wn[u]; }
+#pragma unroll
+                    for (int u = 0; u < RS; u++) { const int h = h0 + 4 * RS + 4 * u + l4, hc = h < N ? h : N - 1; xjn[u] = xj[hc]; xkn[u] = xk[hc]; wn[u] = W.w[hc]; }
+#pragma unroll
+                    for (int u = 0; u < RS; u++) {
+                        const int h = h0 + 4 * u + l4;
+                        if (h0 + 4 * u < Nr) {
+                            const double pj = dv ? xjc[u] / sj : xjc[u] * sj, pk = dv ? xkc[u] / sk : xkc[u] * sk;
+                            const double a = (h < N && ja < Mm) ? pj * wc[u] : 0.0;
+                            const double b = (h < N && kb < Mm) ? pk : 0.0;
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int jm = tj * 16 + l4 + 4 * r, km = tk * 16 + l15;
+                    if (jm < Mm && km < Mm && km <= jm) {
+                        double v = acc[r];
+                        if (jm == km) v += W.A[km];
+                        W.H[(size_t)(km + 1) * ld + jm + 1] = v; W.H[(size_t)(jm + 1) * ld + km + 1] = v;
+                    }
+                }
+            }
+        } else {   // lower triangle of Phi' diag(w) Phi, one wavefront per (j, k) pair
+            const int np = (M - 1) * M / 2;
+            for (int q = B.wave; q < np; q += B.nwave) {
+                int j = (int)((sqrt(8.0 * q + 1.0) - 1.0) * 0.5);
+                while ((j + 1) * (j + 2) / 2 <= q) j++;
+                while (j * (j + 1) / 2 > q) j--;
+                const int k = q - j * (j + 1) / 2 + 1;
+                j += 1;                                        // 1 <= k <= j <= M-1
+                const int uj = W.used[j - 1], uk = W.used[k - 1];
+                double a = 0;
+                for (int h = B.lane; h < N; h += 64) a += bm_col(F, W, N, uj, h) * W.w[h] * bm_col(F, W, N, uk, h);
+                a = wave_sum(a);
+                if (B.lane == 0) {
+                    if (j == k) a += W.A[k - 1];
+                    W.H[(size_t)k * ld + j] = a; W.H[(size_t)j * ld + k] = a;
+                }
+            }
+        }
+}
+
+// bb_i = x_i' diag(w) x_i and ze_i = x_i' e for every feature, when bm_weighted_rows did not deliver them
+DEV void bm_feature_stats(const Blk &B, const FoldDev &F, const BmWork &W, int K, int N, int have_stats)
+{
+    if (!have_stats) {
+        for (int i = B.wave; i < K; i += B.nwave) {
+            const double *x = F.X + (size_t)i * N;
+            double bbq = 0, ze = 0;
+            for (int h = B.lane; h < N; h += 64) { const double xv = x[h]; bbq += W.w[h] * (xv * xv); ze += xv * W.e[h]; }
+            bbq = wave_sum(bbq); ze = wave_sum(ze);
+            if (B.lane == 0) { W.bb[i] = bbq; W.aroot[i] = ze; }
+        }
+    }
+}
+
+// bb[i] = x_i' (w .* phi) / |x_i| for all features and tmp[p] = Phi_p' (w .* phi) for the model columns (bm_add)
+DEV void bm_add_products(const Blk &B, const FoldDev &F, const BmWork &W, int K, int M, int N)
+{
+    // eight features per wave and reduction tree: their loads are in flight together (a feature at a time paid a memory
+    // round trip per feature); wave_sum8 pairs lanes exactly like wave_sum, so the sums are the same bits
+    for (int i0 = B.wave * 8; i0 < K; i0 += B.nwave * 8) {
+        double a[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const double *x = F.X + (size_t)(i0 + c < K ? i0 + c : K - 1) * N;
+            double t = 0;
+            for (int h = B.lane; h < N; h += 64) t += x[h] * W.bphi[h];
+            a[c] = t;
+        }
+        wave_sum8(a, B.lane);
+        const int i = i0 + (B.lane >> 3);
+        if ((B.lane & 7) == 0 && i < K) W.bb[i] = a[0] / F.scale[i];
+    }
+    for (int p = B.wave; p < M; p += B.nwave) {
+        double a = 0;
+        for (int h = B.lane; h < N; h += 64) a += BM_PHI(p, h) * W.bphi[h];
+        a = wave_sum(a);
+        if (B.lane == 0) W.tmp[p] = a;
+    }
+}

@@ -26,29 +26,10 @@
 #include "blk.h"
 #include "types.h"
 
-#if defined(PAREBEN_HOST_EMUL) && defined(PAREBEN_TRACE)
-#include <stdio.h>
-#define GM_TRACE(...) fprintf(stderr, __VA_ARGS__)
-#else
-#define GM_TRACE(...)
-#endif
 
 enum { ACT_NONE = -10, ACT_REEST = 0, ACT_ADD = 1, ACT_DEL = -1, ACT_TERM = 10 };
 enum { UP_FREE = -1, UP_LOST = -2 };
 
-// Optional per-phase tick accumulation (diagnostic build -DPAREBEN_PHASE_TIMERS only; the ticks go
-// to a buffer of their own and never into a result).
-#if defined(PAREBEN_PHASE_TIMERS) && !defined(PAREBEN_HOST_EMUL)
-#define PH_BEGIN() long long ph_t0_ = (B.tid == 0) ? (long long)wall_clock64() : 0
-#define PH_END(k) do { if (B.tid == 0) S.ph[k] += (long long)wall_clock64() - ph_t0_; } while (0)
-#define PHX_BEGIN(v) long long v = (B.tid == 0) ? (long long)wall_clock64() : 0
-#define PHX_END(v, k) do { if (B.tid == 0 && phx) phx[k] += (long long)wall_clock64() - v; } while (0)
-#else
-#define PH_BEGIN() do {} while (0)
-#define PH_END(k) do {} while (0)
-#define PHX_BEGIN(v) do {} while (0)
-#define PHX_END(v, k) do {} while (0)
-#endif
 enum { PH_FS_FEAT = 0, PH_FS_REST = 1, PH_DML = 2, PH_ACTION = 3, PH_NOISE = 4, PH_INVERSE = 5, PH_KSWEEP = 6, PH_TOTAL = 7,
        PH_MATVEC = 8, PH_RANK1 = 9, PH_REFRESH = 10, PH_HBUILD = 11, PH_MU = 12, PH_TRACK = 13, PH_INV_PIVOT = 14, PH_INV_TN = 15,
        PH_FS_MINE = 16, PH_FS_CHUNKS = 17, PH_SQ_MINE = 18, PH_SQ_CHUNKS = 19, PH_FS_WAIT = 20, PH_SQ_WAIT = 21, PH_N = 24 };
@@ -94,440 +75,59 @@ DEVNI void gm_refresh_out(const Blk &B, const GmWork &W, int K)
     blk_sync(B);
 }
 
-#ifdef PAREBEN_HOST_EMUL
-typedef double *lptr_d;
-#else
-// address-space-qualified views (global_load / ds_read instead of flat_load) for the hot loops
-typedef const double __attribute__((address_space(1))) *gptr_cd;
-typedef const char __attribute__((address_space(1))) *gptr_cc;
-typedef const int __attribute__((address_space(1))) *gptr_ci;
-typedef double __attribute__((address_space(1))) *gptr_d;
-typedef int __attribute__((address_space(3))) *lptr_i;
-typedef double __attribute__((address_space(3))) *lptr_d;
-typedef double d4 __attribute__((ext_vector_type(4)));
-DEV gptr_cd as_global(const double *p) { return (gptr_cd)p; }
-DEV gptr_ci as_global(const int *p) { return (gptr_ci)p; }
-DEV lptr_d as_lds(double *p) { return (lptr_d)p; }
-DEV lptr_i as_lds(int *p) { return (lptr_i)p; }
-DEV gptr_d as_global_rw(double *p) { return (gptr_d)p; }
-// Arguments of non-inlined device functions arrive in VGPRs; these put wave-uniform values back
-// into SGPRs so addresses become "scalar base + 32-bit lane offset" (fewer VGPRs, saddr loads).
-DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-template <class T> DEV T *uni_ptr(T *p)
+// S_in / Q_in update of feature i from a = sum_j G[used[j], i] * vec[j].
+// mode 0: re-estimate (:577-587), 1: add (:1699-1711), 2: delete (:1800-1808).
+DEV void gm_sq_apply(const GmWork &W, int mode, double beta, double c1, double c2, const double *newrow, int i, double a)
 {
-    const unsigned long long v = (unsigned long long)p;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return (T *)(((unsigned long long)hi << 32) | lo);
-}
-#ifndef FS_NB
-#define FS_NB 2            // 16-feature column blocks per wave: every Sigma panel read from LDS feeds FS_NB matrix ops
-#endif
-#define FS_TPP (16 / FS_NB) // row tiles of Sigma per pass (FS_NB x FS_TPP accumulator tiles per wave)
-#ifndef FS_NWAVES
-#define FS_NWAVES 8        // wavefronts per fit workgroup (set by the kernel file from FIT_THREADS)
-#endif
-#define FS_FT (16 * FS_NWAVES * FS_NB)   // features per tile: every wave owns FS_NB 16-feature column blocks of it
-#define SQ_FT 128          // feature tile of the shared action mat-vecs (job board granularity)
-#ifndef FS_APRE
-#define FS_APRE 1           // tiles by which the LDS reads of the A operands run ahead of the matrix ops
-#endif
-#define FS_PPW (FS_TPP / FS_NWAVES)   // Sigma panels each wave stages per step
-#define FS_MAX_M 2048      // largest active set the pass is laid out for (LDS: row offsets + mu); the host bounds every capacity by it
-static_assert(FS_TPP % FS_NWAVES == 0 && 16 % FS_NB == 0, "full-stat tiling");
-
-// The full-stat pass is ONE software pipeline over all (feature tile, pass, k-block) steps of a call:
-// a cursor names the step; what a step needs from memory is requested one (Gram operands) or two
-// (Sigma panels) steps ahead, across pass and tile boundaries, so memory latency is exposed once per call.
-struct FsCur { int i0, pass, h, last; };          // feature tile origin, row-tile pass, k-block, last k-block of the pass
-// Row tiles are cut into passes of at most FS_TPP; a pass visits the k-blocks 0 .. (its last tile), so the number of
-// steps of a feature tile is the sum of the passes' end indices: smallest when the LATER passes are full and the
-// first one takes the remainder (19 tiles: 3 + 8 + 8 -> 3 + 11 + 19 = 33 steps; 7 + 6 + 6 would be 39, 8 + 8 + 3: 43).
-// `first` = tiles of pass 0.
-DEV int fs_pass_begin(int pass, int first) { return pass == 0 ? 0 : first + (pass - 1) * FS_TPP; }
-DEV int fs_pass_end(int pass, int first) { return first + pass * FS_TPP; }          // exclusive; the last pass ends at nJ
-DEV void fs_advance(FsCur &c, int n_pass, int nJ, int first)
-{
-    c.h++;
-    if (c.h > c.last) {
-        c.h = 0;
-        c.pass++;
-        if (c.pass == n_pass) { c.pass = 0; c.i0 += FS_FT; }
-        (void)nJ;
-        c.last = fs_pass_end(c.pass, first) - 1;
+    if (mode == 0) {                             // c1 = kappa, c2 = mu_jj
+        const double ba = beta * a;
+        W.Sin[i] = W.Sin[i] + ba * ba * c1;
+        W.Qin[i] = W.Qin[i] + beta * c2 * c1 * a;
+    } else if (mode == 1) {                      // c1 = s_ii, c2 = mu_i
+        const double mc = beta * newrow[i] - beta * a;
+        W.Sin[i] = W.Sin[i] - mc * mc * c1;
+        W.Qin[i] = W.Qin[i] - c2 * mc;
+    } else {                                     // c1 = Sigma_jj, c2 = (int) mu_jj
+        const double ba = beta * a;
+        W.Sin[i] = W.Sin[i] + ba * ba / c1;
+        W.Qin[i] = W.Qin[i] + ba * c2 / c1;
     }
 }
 
-// One step = k-block h (16 rows of the active set) of one pass (<= FS_TPP row tiles of Sigma) of one
-// feature tile.  T = Sigma * Bt on the FP64 matrix cores (v_mfma_f64_16x16x4_f64) in 16 x 16 tiles:
-//   A (16 rows of Sigma x 4 k):  lane l holds A[row = l & 15][k = l >> 4]
-//   B (4 k x 16 features):       lane l holds B[k = l >> 4][col = l & 15]
-//   D register r of lane l:      T[row = (l >> 4) + 4 r][col = l & 15]
-// Work split: every wave owns FS_NB 16-feature column blocks of the tile and ALL row tiles of the pass
-// (FS_NB x FS_TPP accumulator tiles), so at every step all waves do the same number of matrix ops -- the
-// triangular schedule below costs no balance -- and every A operand read feeds FS_NB matrix ops.
-// A operand: the Sigma panels of the step ((tile J, k-block h) = 16 x 16) are identical for all waves, so
-// they are staged once per workgroup through LDS, in operand order (a wave reads one contiguous 512 B line
-// per operand); each Sigma element is fetched from memory once per workgroup and step.
-// B operand: lane l of k-group s holds G[row 16 h + 4 s + (l >> 4)][feature 16 blk + (l & 15)] -- 16
-// consecutive features of one Gram row per 16 lanes, i.e. whole 128-byte lines -- and a wave needs only its
-// own column blocks, so the Gram block is not shared through LDS at all: each wave loads its operands for
-// step g+1 straight into a register ring during step g (loff[p] = byte offset of Gram row p of the active
-// set).  Rows >= M are zeroed when they are used; the Sigma entries of the ragged 16-block beyond the active
-// set are multiplied by those zeros, so they must be finite: gm_fullstat clears that band before every pass
-// (whatever an earlier fit of this workgroup left there -- possibly NaN -- never reaches a result).
-// Sigma is symmetric: row tile J only visits k-blocks h <= J and counts h < J twice (the panel is
-// doubled when it is staged; doubling is exact).
-// When h == J the k-block on the diagonal IS tile J's own rows, and the rows a lane holds as B operand
-// (4 s + l4) are exactly the rows of its accumulator registers (l4 + 4 r): the wave folds
-// sum_j T[j][i] b_j[i] and sum_j b_j[i] mu_j for its features right there from registers and clears the tile.
-//   * panel ring slot CUR (= g & 1) receives the loads of step g+2 (cursor c2); slot CUR^1 holds step g+1's
-//     panels (requested during step g-1), which this step writes to the other LDS buffer.
-// Uniform branches guard matrix ops, folds and LDS writes only -- never a load -- so the load/wait
-// bookkeeping is the same on every path (counted s_waitcnt vmcnt(N); the function must not spill and
-// nothing may be pending at loop entry, or the compiler puts a static vmcnt(0) inside the loop).
-typedef const unsigned long long __attribute__((address_space(3))) *lptr_cull;
-template <int CUR>
-DEV void fs_step(gptr_cc Sig, gptr_cc G, lptr_cull loff, lptr_d lmu, lptr_d acur, lptr_d anxt,
-                   int ld, const FsCur &c0, const FsCur &c1, const FsCur &c2, int first, int nJ, int M, int K, int wave, int lane,
-                   double (&pa)[2][FS_PPW][4], double (&bvr)[2][FS_NB][4], d4 (&acc)[FS_NB][FS_TPP], double (&qsum)[FS_NB],
-                   double (&msum)[FS_NB])
+// Sigma <- H^-1 for the SPD M x M matrix held in Sig (in place, Gauss-Jordan without pivoting:
+// the pivots are the Cholesky pivots squared, so a non-positive pivot means "not SPD").
+// Stands in for dpotrf+dpotri (:1346-1369).  Returns 0 on success.
+DEVNI int gm_spd_inverse_scalar(const Blk &B, const GmWork &W, int M)
 {
-    constexpr int NX = CUR ^ 1;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    // ---- matrix ops of step g; rows beyond the active set contribute zero
-    const int jb = fs_pass_begin(c0.pass, first), je = fs_pass_end(c0.pass, first);
-    double bv[FS_NB][4];
-#pragma unroll
-    for (int s = 0; s < 4; s++) {
-        const bool live = c0.h * 16 + 4 * s + l4 < M;
-#pragma unroll
-        for (int nb = 0; nb < FS_NB; nb++) bv[nb][s] = live ? bvr[CUR][nb][s] : 0.0;
-    }
-    // The A operands of tile t+1 are read from LDS before the matrix ops of tile t are issued (FS_APRE tiles ahead
-    // through a small register ring), so no LDS latency sits between two tiles' matrix ops; the reads are
-    // unconditional (every slot of the buffer is addressable), only the matrix ops are guarded.
-    double an[FS_APRE][4];
-#pragma unroll
-    for (int p = 0; p < FS_APRE; p++)
-#pragma unroll
-        for (int s = 0; s < 4; s++) an[p][s] = acur[(p * 4 + s) * 64 + lane];
-#pragma unroll
-    for (int t = 0; t < FS_TPP; t++) {
-        const int J = jb + t;
-        double ac[4];
-#pragma unroll
-        for (int s = 0; s < 4; s++) ac[s] = an[t % FS_APRE][s];
-        if (t + FS_APRE < FS_TPP) {
-#pragma unroll
-            for (int s = 0; s < 4; s++) an[t % FS_APRE][s] = acur[((t + FS_APRE) * 4 + s) * 64 + lane];
-        }
-        // ---- requests, placed behind work that is already queued so that their address arithmetic and the LDS read of
-        // the row offsets do not hold up the first matrix ops of the step: this wave's share of the Sigma panels of
-        // step g+2 in front of tile 0 ...
-        if (t == 0) {
-            const unsigned lane_off = (unsigned)((l4 * ld + l15) * 8);
-#pragma unroll
-            for (int pi = 0; pi < FS_PPW; pi++) {
-                const int t2 = wave + pi * FS_NWAVES, J2 = fs_pass_begin(c2.pass, first) + t2;
-                const bool on = J2 < fs_pass_end(c2.pass, first) && c2.h <= J2;
-                const unsigned o = on ? (unsigned)((c2.h * 16 * ld + J2 * 16) * 8) + lane_off : 0u;
-                const unsigned st = on ? (unsigned)(4 * ld * 8) : 0u;
-#pragma unroll
-                for (int s = 0; s < 4; s++) pa[CUR][pi][s] = *(gptr_cd)(Sig + (o + s * st));
-            }
-        }
-        if (t == 1) {                                         // ... and its own Gram operands of step g+1 behind tile 0's matrix ops
-#pragma unroll
-            for (int s = 0; s < 4; s++) {
-                const unsigned long long ro = loff[c1.h * 16 + 4 * s + l4];
-#pragma unroll
-                for (int nb = 0; nb < FS_NB; nb++) {
-                    const int i = c1.i0 + 16 * (wave + nb * FS_NWAVES) + l15;
-                    bvr[NX][nb][s] = *(gptr_cd)(G + (ro + (unsigned)((i < K ? i : K - 1) * 8)));
-                }
-            }
-        }
-        if (J < je && c0.h <= J) {
-#pragma unroll
-            for (int s = 0; s < 4; s++) {
-                const double a = ac[s];
-#pragma unroll
-                for (int nb = 0; nb < FS_NB; nb++) acc[nb][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[nb][s], acc[nb][t], 0, 0, 0);
-            }
-            if (c0.h == J) {                                  // tile J is complete: fold and clear
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const double mj = lmu[c0.h * 16 + l4 + 4 * r];
-#pragma unroll
-                    for (int nb = 0; nb < FS_NB; nb++) {
-                        qsum[nb] += acc[nb][t][r] * bv[nb][r];
-                        msum[nb] += bv[nb][r] * mj;
-                    }
-                }
-#pragma unroll
-                for (int nb = 0; nb < FS_NB; nb++) acc[nb][t] = d4{0, 0, 0, 0};
-            }
-        }
-    }
-    // ---- step g+1's Sigma panels (requested during step g-1) -> the other LDS buffer
-#pragma unroll
-    for (int pi = 0; pi < FS_PPW; pi++) {
-        const int t = wave + pi * FS_NWAVES, J = fs_pass_begin(c1.pass, first) + t;
-        const double w = c1.h < J ? 2.0 : 1.0;
-#pragma unroll
-        for (int s = 0; s < 4; s++) {
-            double v = pa[NX][pi][s] * w;
-            asm volatile("" : "+v"(v));                        // consume the load on every path (see above)
-            if (J < fs_pass_end(c1.pass, first) && c1.h <= J) anxt[(t * 4 + s) * 64 + lane] = v;
-        }
-    }
-}
-
-#endif
-
-// S_in[i] = beta - beta^2 b_i' Sigma b_i,  Q_in[i] = beta (bt_i - b_i' mu)  for every feature,
-// b_i = G[used, i].  MainEff.c:1291-1319.  This is the K*M^2 contraction that dominates the
-// run time; lanes run over features (coalesced Gram rows), each wavefront owns
-// 8 rows of Sigma per pass and the Gram tile is staged through LDS once per pass.
-DEVNI void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W, int K, int M,
-                              double beta, int tile0, int tile1)
-{
-#ifdef PAREBEN_HOST_EMUL
     const int ld = W.ld;
-    (void)tile0; (void)tile1;
-    for (int i = 0; i < K; i++) {
-        double quad = 0, bm = 0;
-        for (int j = 0; j < M; j++) {
-            double a = 0;
-            for (int p = 0; p < M; p++) a += F.G[(size_t)W.rowid[p] * K + i] * W.Sig[(size_t)j * ld + p];
-            double bj = F.G[(size_t)W.rowid[j] * K + i];
-            quad += a * bj;
-            bm += bj * W.mu[j];
-        }
-        W.Sin[i] = beta - beta * quad * beta;
-        W.Qin[i] = beta * (W.bt[i] - bm);
-    }
-#else
-    // see fs_step.  B lives in memory (reference argument of a non-inlined function): take register
-    // copies once, or every use in the loop becomes a flat load followed by s_waitcnt vmcnt(0); results
-    // leave through global-address-space pointers for the same reason.
-    const int lane = B.lane, wave = uni(B.wave), tid = B.tid, nthr = uni(B.nthr);
-    const gptr_cc Sig = (gptr_cc)as_global(uni_ptr(W.Sig));
-    const gptr_cc G = (gptr_cc)as_global(uni_ptr(F.G));
-    const gptr_d gSin = as_global_rw(uni_ptr(W.Sin)), gQin = as_global_rw(uni_ptr(W.Qin));
-    const gptr_cd gbt = as_global(uni_ptr(W.bt));
-    double *pool = uni_ptr(B.pool);
-    const lptr_d la = as_lds(pool);                                         // 2 x FS_TPP x 256 staged Sigma panels
-    unsigned long long *loff_w = (unsigned long long *)(pool + 2 * FS_TPP * 256);          // Gram row byte offsets, M <= FS_MAX_M
-    const lptr_cull loff = (lptr_cull)loff_w;
-    const lptr_d lmu = as_lds(pool + 2 * FS_TPP * 256 + FS_MAX_M);          // mu, zero-padded to a k-block
-    K = uni(K); M = uni(M);
-    const int ld = uni(W.ld);
-    const int nJ = (M + 15) >> 4;
-    const int n_pass = (nJ + FS_TPP - 1) / FS_TPP;
-    const int first = nJ - (n_pass - 1) * FS_TPP;     // row tiles of pass 0; the later passes are full (see fs_pass_end)
-    const int n_ft = uni(tile1) - uni(tile0);                               // feature tiles tile0 .. tile1-1 of the call
-    const int i_begin = uni(tile0) * FS_FT;
-    int steps_per_tile = 0;
-    for (int p = 0; p < n_pass; p++) steps_per_tile += fs_pass_end(p, first);
-    const int total = n_ft * steps_per_tile;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    __syncthreads();
-    for (int p = tid; p < nJ * 16; p += nthr) {
-        loff_w[p] = (unsigned long long)W.rowid[p < M ? p : 0] * (unsigned long long)K * 8ull;
-        lmu[p] = p < M ? W.mu[p] : 0.0;
-    }
-    __syncthreads();
-    FsCur c0, c1, c2;
-    c0.i0 = i_begin; c0.pass = 0; c0.h = 0; c0.last = first - 1;
-    c1 = c0; fs_advance(c1, n_pass, nJ, first);
-    c2 = c1; fs_advance(c2, n_pass, nJ, first);
-    d4 acc[FS_NB][FS_TPP];
-#pragma unroll
-    for (int nb = 0; nb < FS_NB; nb++)
-#pragma unroll
-        for (int t = 0; t < FS_TPP; t++) acc[nb][t] = d4{0, 0, 0, 0};
-    double pa[2][FS_PPW][4], bvr[2][FS_NB][4];
-    double qsum[FS_NB], msum[FS_NB];
-#pragma unroll
-    for (int nb = 0; nb < FS_NB; nb++) { qsum[nb] = 0; msum[nb] = 0; }
-    {   // pipeline fill: step 0's Gram operands into ring slot 0, its Sigma panels straight to LDS buffer 0,
-        // step 1's panels into ring slot 1
-        const unsigned lane_off = (unsigned)((l4 * ld + l15) * 8);
-#pragma unroll
-        for (int s = 0; s < 4; s++) {
-            const unsigned long long ro = loff[4 * s + l4];
-#pragma unroll
-            for (int nb = 0; nb < FS_NB; nb++) {
-                const int i = i_begin + 16 * (wave + nb * FS_NWAVES) + l15;
-                bvr[0][nb][s] = *(gptr_cd)(G + (ro + (unsigned)((i < K ? i : K - 1) * 8)));
+    for (int k = 0; k < M; k++) {
+        PAR(i, M) { W.v3[i] = W.Sig[(size_t)k * ld + i]; W.v4[i] = W.Sig[(size_t)i * ld + k]; }
+        blk_sync(B);
+        const double d = W.v3[k];
+        if (!(d > 0)) return 1;
+        const double rd = 1.0 / d;
+        for (int j = B.wave; j < M; j += B.nwave) {
+            const double rkj = W.v4[j] * rd;
+            for (int i = B.lane; i < M; i += BLK_LANES) {
+                double a;
+                if (i == k) a = (j == k) ? rd : rkj;
+                else if (j == k) a = -W.v3[i] * rd;
+                else a = W.Sig[(size_t)j * ld + i] - W.v3[i] * rkj;
+                W.Sig[(size_t)j * ld + i] = a;
             }
         }
-#pragma unroll
-        for (int pi = 0; pi < FS_PPW; pi++) {
-            const int t = wave + pi * FS_NWAVES;
-            const int J1 = fs_pass_begin(c1.pass, first) + t;
-            const bool on0 = t < first, on1 = J1 < fs_pass_end(c1.pass, first) && c1.h <= J1;
-            const unsigned o0 = on0 ? (unsigned)(t * 16 * 8) + lane_off : 0u, st0 = on0 ? (unsigned)(4 * ld * 8) : 0u;
-            const unsigned o1 = on1 ? (unsigned)((c1.h * 16 * ld + J1 * 16) * 8) + lane_off : 0u, st1 = on1 ? (unsigned)(4 * ld * 8) : 0u;
-#pragma unroll
-            for (int s = 0; s < 4; s++) {
-                const double v0 = *(gptr_cd)(Sig + (o0 + s * st0));
-                pa[1][pi][s] = *(gptr_cd)(Sig + (o1 + s * st1));
-                if (on0) la[(t * 4 + s) * 64 + lane] = v0 * (0 < t ? 2.0 : 1.0);
-            }
-        }
+        blk_sync(B);
     }
-    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): nothing pending at loop entry; the compiler tracks this form
-    __syncthreads();
-    // After the last step of a feature tile every wave holds the sums of its features, spread over
-    // the four row groups of the accumulator layout: two xor-shuffles, then lanes 0..15 write them.
-#define FS_FINISH_TILE(cc)                                                                                           \
-        if ((cc).h == (cc).last && (cc).pass == n_pass - 1) {                                                        \
-            _Pragma("unroll") for (int nb = 0; nb < FS_NB; nb++) {                                                   \
-                double q = qsum[nb], m = msum[nb];                                                                   \
-                q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);                                              \
-                m += __shfl_xor(m, 16, 64); m += __shfl_xor(m, 32, 64);                                              \
-                const int i = (cc).i0 + 16 * (wave + nb * FS_NWAVES) + l15;                                          \
-                if (lane < 16 && i < K) { gSin[i] = beta - beta * q * beta; gQin[i] = beta * (gbt[i] - m); }         \
-                qsum[nb] = 0; msum[nb] = 0;                                                                          \
-            }                                                                                                        \
-        }
-#define FS_STEP(CURSLOT, gg)                                                                                         \
-        {                                                                                                            \
-            const int cb = (gg) & 1, nb_ = cb ^ 1;                                                                   \
-            fs_step<CURSLOT>(Sig, G, loff, lmu, la + cb * (FS_TPP * 256), la + nb_ * (FS_TPP * 256), ld, c0, c1, c2, \
-                               first, nJ, M, K, wave, lane, pa, bvr, acc, qsum, msum);                                 \
-            FS_FINISH_TILE(c0)                                                                                       \
-            __syncthreads();                                                                                         \
-            c0 = c1; c1 = c2; fs_advance(c2, n_pass, nJ, first);                                                       \
-        }
-    // whole pairs of steps without any skip path inside the loop (a skipped step would leave its
-    // predecessor's prefetch pending on the back edge: static s_waitcnt vmcnt(0)); then the odd tail
-    int g = 0;
-    for (; g + 1 < total; g += 2) {
-        FS_STEP(0, g)
-        FS_STEP(1, g + 1)
-    }
-    if (g < total) FS_STEP(0, g)
-#undef FS_STEP
-#undef FS_FINISH_TILE
-#endif
-    blk_sync(B);
+    return 0;
 }
 
-// ---- shared phases ------------------------------------------------------------------------------
-// A fit is one workgroup, and the heaviest fits of a grid take tens of times the median; once the
-// work queue is drained the workgroups that are out of fits would sit idle while those finish.  The
-// full-stat pass (half of a heavy fit's time) and the K x M mat-vec of every action are independent
-// per feature, so in that phase of the launch an owner OPENS each of them (FsJob): idle workgroups
-// claim chunks of feature tiles (FS_FT or SQ_FT features each) by compare-and-swap on (epoch, next tile), run the same code on
-// the owner's state in HBM (Sigma / mu / row ids, or the action's vector) and write S_in / Q_in for
-// their features; the owner works on its own job too and waits for the chunk count.  Results do not
-// depend on who computed a feature (same code, same order).
-// Visibility follows the guide's hand-off recipe both ways: stores drained by every wave, barrier,
-// one agent-scope release, then a relaxed atomic; consumers read the atomic relaxed, then one
-// agent-scope acquire + s_waitcnt vmcnt(0) + barrier before plain loads.  Nobody waits while holding
-// a chunk, so every wait ends; the owner's wait is bounded anyway and flags the fit if it expires.
-#ifndef PAREBEN_HOST_EMUL
-#define FS_CHUNK (4 / FS_NB) // tiles per claim, full-stat pass (512 features)
-#define SQ_CHUNK 8         // tiles per claim, action mat-vec (1024 features = one pair per thread)
-#define AT_LOAD(p) __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define AT_STORE(p, v) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define AT_ADD(p, v) __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-DEV bool fs_epoch_open(unsigned long long w) { return (w >> 32) & 1; }
-// tiles per claim: a full-stat tile of a large active set is long enough (0.1 ms and up) to be claimed on its own,
-// which is what lets a whole idle GPU work on the one heavy fit left on it
-DEV int job_chunk(int kind, int M) { return kind != JOB_FULLSTAT ? SQ_CHUNK : FS_CHUNK; }
-// thread 0 only: first tile of the claimed chunk, or -1 when the job is closed / fully handed out
-DEV int fs_claim(FsJob *job, int n_tiles, int chunk)
-{
-    for (;;) {
-        unsigned long long w = AT_LOAD(&job->word);
-        if (!fs_epoch_open(w) || (int)(unsigned)w >= n_tiles) return -1;
-        if (__hip_atomic_compare_exchange_strong(&job->word, &w, w + chunk, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            return (int)(unsigned)w;
-    }
-}
-// Owner side.  Returns false when sharing is off / not worth it (the caller then does the whole phase);
-// otherwise opens the job, runs work(tile0, tile1) on the chunks it claims itself, waits for the rest.
-template <class Work>
-DEV bool job_share(const Blk &B, GmScalars &S, int kind, int M, int n_tiles, double beta, int mode, int rid, int aux, double c1,
-                   double c2, Work work)
-{
-    const FsShare *sh = S.share;
-    const int chunk = job_chunk(kind, M);
-    if (!(sh && sh->jobs) || n_tiles < 4 * chunk) return false;
-    __syncthreads();
-    // somebody may be free to help: always in the tail; from the start when the launch is small or the fit is a
-    // heavy one (large active set: the few fits that decide the step time once the work is spread over GPUs)
-    if (B.tid == 0) B.ired[0] = sh->early || M >= sh->heavy_m || AT_LOAD(sh->queue) >= sh->n_units;
-    __syncthreads();
-    const bool open = B.ired[0] != 0;
-    __syncthreads();
-    if (!open) return false;
-    FsJob *job = sh->jobs + sh->self;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // what the phase reads: every wave drains its stores
-    __syncthreads();
-    if (B.tid == 0) {
-        AT_STORE(&job->done, 0); AT_STORE(&job->fold, S.fold); AT_STORE(&job->M, M); AT_STORE(&job->n_tiles, n_tiles);
-        AT_STORE(&job->kind, kind); AT_STORE(&job->mode, mode); AT_STORE(&job->rid, rid); AT_STORE(&job->pad, aux);
-        __hip_atomic_store(&job->beta, beta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&job->c1, c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&job->c2, c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned long long w = AT_LOAD(&job->word);
-        AT_STORE(&job->word, ((w >> 32) + 1) << 32);           // odd epoch, next tile 0: open
-    }
-    __syncthreads();
-    int mine = 0;
-    for (;;) {
-        if (B.tid == 0) B.ired[0] = fs_claim(job, n_tiles, chunk);
-        __syncthreads();
-        const int c = B.ired[0];
-        __syncthreads();
-        if (c < 0) break;
-        work(c, c + chunk < n_tiles ? c + chunk : n_tiles);
-        mine++;
-    }
-    if (B.tid == 0) {
-        const int total = (n_tiles + chunk - 1) / chunk;
-        AT_ADD(&job->done, mine);
-        long spins = 0;
-#ifdef PAREBEN_PHASE_TIMERS
-        const long long tw0 = (long long)wall_clock64();
+// ---- the phases: everything whose implementation is the hardware mapping (matrix-core passes, LDS staging, the job
+// board, address-space-qualified loads).  The shipped library gets gm_dev.h; the CPU test harness under tests/emul, which
+// steps this file's control flow without a GPU, names its own header of plain loops with the same signatures instead.
+#ifndef GM_PHASES_H
+#define GM_PHASES_H "gm_dev.h"
 #endif
-        while (AT_LOAD(&job->done) < total && spins < 200000000L) { __builtin_amdgcn_s_sleep(4); spins++; }
-#ifdef PAREBEN_PHASE_TIMERS
-        const int fsj = kind == JOB_FULLSTAT;
-        S.ph[fsj ? PH_FS_MINE : PH_SQ_MINE] += mine; S.ph[fsj ? PH_FS_CHUNKS : PH_SQ_CHUNKS] += total;
-        S.ph[fsj ? PH_FS_WAIT : PH_SQ_WAIT] += (long long)wall_clock64() - tw0;
-#endif
-        B.ired[0] = AT_LOAD(&job->done) >= total;
-        const unsigned long long w = AT_LOAD(&job->word);
-        AT_STORE(&job->word, ((w >> 32) + 1) << 32);           // even epoch: closed
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // the helpers' S_in / Q_in
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-    if (!B.ired[0]) S.status |= ST_ABORT;
-    __syncthreads();
-    return true;
-}
-#endif
-
-DEVNI void gm_fullstat_pass(const Blk &B, const FoldDev &F, const GmWork &W, int K, int M, double beta, GmScalars &S)
-{
-#ifdef PAREBEN_HOST_EMUL
-    const int n_tiles = 1;                                    // the host build has no tiles: one call does all features
-#else
-    const int n_tiles = (K + FS_FT - 1) / FS_FT;
-    if (M >= 48 && job_share(B, S, JOB_FULLSTAT, M, n_tiles, beta, 0, -1, -1, 0.0, 0.0,
-                             [&](int t0, int t1) { gm_fullstat_features(B, F, W, K, M, beta, t0, t1); })) return;
-#endif
-    gm_fullstat_features(B, F, W, K, M, beta, 0, n_tiles);
-}
+#include GM_PHASES_H
 
 // Full statistics, MainEff.c:1209-1341 (Q3: gamma[0] is left alone).
 DEV void gm_fullstat(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScalars &S,
@@ -549,34 +149,18 @@ DEV void gm_fullstat(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmS
         W.mu[i] = a * beta;
         if (i >= 1) W.gam[i] = 1 - W.Sig[(size_t)i * ld + i] * W.A[i];
     }
-#ifndef PAREBEN_HOST_EMUL
-    {   // the band between the active block and the next multiple of 16 (see fs_step): exact zeros for the matrix-core pass
-        const int Mp = ((M + 15) >> 4) << 4, pad = Mp - M;
-        for (int e = B.tid; e < Mp * pad; e += B.nthr) {
-            const int j = e / pad, i = M + e - j * pad;
-            W.Sig[(size_t)j * ld + i] = 0.0;
-            W.Sig[(size_t)i * ld + j] = 0.0;
-        }
-    }
-#endif
+    gm_fs_pad(B, W, M);                                       // matrix-core pass: exact zeros in the ragged 16-block (gm_dev.h)
     blk_sync(B);
     {
         PH_BEGIN();
-#if defined(PAREBEN_PHASE_TIMERS) && !defined(PAREBEN_HOST_EMUL)
-        const long long ck0 = (B.tid == 0) ? (long long)clock64() : 0;
-#endif
+        GM_FS_CLOCK_BEGIN();
         gm_fullstat_pass(B, F, W, K, M, beta, S);
-#if defined(PAREBEN_PHASE_TIMERS) && !defined(PAREBEN_HOST_EMUL)
-        if (B.tid == 0) S.ph[PH_FS_REST] += (long long)clock64() - ck0;     // shader-clock ticks of the same span
-#endif
+        GM_FS_CLOCK_END();
         PH_END(PH_FS_FEAT);
     }
     gm_refresh_out(B, W, K);
     CNT(c.n_fullstat++; c.sum_m_full += M; c.sum_m2_full += (int64_t)M * M);
-#ifndef PAREBEN_HOST_EMUL
-    // matrix-core work of the pass: per 16-feature block the triangle of (row tile J, k-block h <= J) tile products
-    CNT(const int64_t nJ = (M + 15) >> 4; c.mfma_tiles += (int64_t)((K + FS_FT - 1) / FS_FT) * (FS_FT / 16) * (nJ * (nJ + 1) / 2));
-#endif
+    gm_fs_count(B, S, K, M);
 }
 
 // Per-feature marginal-likelihood change and action, MainEff.c:1372-1582.  Returns the arg-max
@@ -592,12 +176,6 @@ DEVNI int gm_delta_ml(const Blk &B, const GmWork &W, int K, int N, int M, double
              : (M > 100 || M >= N || residual <= varY * 0.1)) { prio_add = 0; prio_del = 1; }
     int my_add = 0, my_del = 0;
     double v1 = 0; int idx1 = 0x7fffffff;                     // arg-max of this pass (valid when no rescan follows)
-#ifdef PAREBEN_HOST_EMUL
-    PAR(i, K) {
-        const int l = W.upos[i];
-        if (l == UP_LOST) { W.act[i] = ACT_NONE; continue; }   // in neither list: stale dML stays
-        const double so = W.Sout[i], qo = W.Qout[i];
-#else
     // the three loads of the next feature are issued before the (long) arithmetic of this one
     const gptr_ci g_upos = as_global(W.upos);
     const gptr_cd g_so = as_global(W.Sout), g_qo = as_global(W.Qout);
@@ -608,7 +186,6 @@ DEVNI int gm_delta_ml(const Blk &B, const GmWork &W, int K, int N, int M, double
         const double so = so_n, qo = qo_n;
         { const int in = i + B.nthr; if (in < K) { l_n = g_upos[in]; so_n = g_so[in]; qo_n = g_qo[in]; } }
         if (l == UP_LOST) { W.act[i] = ACT_NONE; continue; }   // in neither list: stale dML stays
-#endif
         double d_ml = 0;
         int act = ACT_NONE;
         const double a = so - qo * qo + 2 * l1 + l2;
@@ -678,19 +255,6 @@ DEVNI int gm_delta_ml(const Blk &B, const GmWork &W, int K, int N, int M, double
 // ordered list of features with dML >= cutoff (ascending index), MainEff.c:463-473
 DEVNI int gm_collect(const Blk &B, const GmWork &W, int K, double cutoff)
 {
-#ifdef PAREBEN_HOST_EMUL
-    int base = 0;
-    for (int i0 = 0; i0 < K; i0 += B.nthr) {
-        const int i = i0 + B.tid;
-        const int f = (i < K && W.dml[i] >= cutoff) ? 1 : 0;
-        int tot;
-        const int off = blk_scan_excl(B, f, &tot);
-        if (f) W.todo[base + off] = i;
-        base += tot;
-    }
-    blk_sync(B);
-    return base;
-#else
     // every thread takes a contiguous slice of the features: one count, ONE block scan, one ordered write
     const int per = (K + B.nthr - 1) / B.nthr, i0 = B.tid * per, i1 = i0 + per < K ? i0 + per : K;
     const gptr_cd dml = as_global(W.dml);
@@ -701,202 +265,6 @@ DEVNI int gm_collect(const Blk &B, const GmWork &W, int K, double cutoff)
     if (n) for (int i = i0; i < i1; i++) if (dml[i] >= cutoff) W.todo[off++] = i;
     blk_sync(B);
     return tot;
-#endif
-}
-
-// S_in / Q_in update of feature i from a = sum_j G[used[j], i] * vec[j].
-// mode 0: re-estimate (:577-587), 1: add (:1699-1711), 2: delete (:1800-1808).
-DEV void gm_sq_apply(const GmWork &W, int mode, double beta, double c1, double c2, const double *newrow, int i, double a)
-{
-    if (mode == 0) {                             // c1 = kappa, c2 = mu_jj
-        const double ba = beta * a;
-        W.Sin[i] = W.Sin[i] + ba * ba * c1;
-        W.Qin[i] = W.Qin[i] + beta * c2 * c1 * a;
-    } else if (mode == 1) {                      // c1 = s_ii, c2 = mu_i
-        const double mc = beta * newrow[i] - beta * a;
-        W.Sin[i] = W.Sin[i] - mc * mc * c1;
-        W.Qin[i] = W.Qin[i] - c2 * mc;
-    } else {                                     // c1 = Sigma_jj, c2 = (int) mu_jj
-        const double ba = beta * a;
-        W.Sin[i] = W.Sin[i] + ba * ba / c1;
-        W.Qin[i] = W.Qin[i] + ba * c2 / c1;
-    }
-}
-
-#ifndef PAREBEN_HOST_EMUL
-// Features [f0, f1) (f0 even, f1 <= K & ~1) of the K x M mat-vec over Gram rows + the S/Q update.  Row ids
-// and `vec` are already staged in LDS.  Every thread owns SQ_Q PAIRS of adjacent features and fetches
-// each pair with one 16-byte load (row base in SGPRs + 32-bit lane offset); NR rows per trip, so
-// SQ_Q * NR independent coalesced 1 KB row segments per wave are in flight.  The sum of a feature runs
-// over the rows in order whatever SQ_Q / NR are.
-template <int SQ_Q, int NR>
-DEV void gm_sq_core(gptr_cc G, lptr_d lvec, lptr_i lused, const GmWork &W, int K, int M, int mode, double beta, double c1,
-                    double c2, const double *newrow, int f0, int f1, int tid, int nthr)
-{
-    typedef double d2 __attribute__((ext_vector_type(2), aligned(8)));   // rows of an odd-K matrix start 8 bytes off
-    typedef const d2 __attribute__((address_space(1))) *gptr_cd2;
-    for (int ib = f0; ib < f1; ib += 2 * SQ_Q * nthr) {
-        d2 accq[SQ_Q];
-        unsigned off[SQ_Q];
-#pragma unroll
-        for (int q = 0; q < SQ_Q; q++) {
-            accq[q] = d2{0, 0};
-            const int i = ib + 2 * (q * nthr + tid);
-            off[q] = (unsigned)((i < f1 ? i : f1 - 2) * 8);
-        }
-        int j = 0;
-        for (; j + NR - 1 < M; j += NR) {
-            d2 g[NR][SQ_Q];
-            double v[NR];
-#pragma unroll
-            for (int r = 0; r < NR; r++) {
-                const gptr_cc row = G + (size_t)uni(lused[j + r]) * (size_t)K * 8;
-                v[r] = lvec[j + r];
-#pragma unroll
-                for (int q = 0; q < SQ_Q; q++) g[r][q] = *(gptr_cd2)(row + off[q]);
-            }
-#pragma unroll
-            for (int r = 0; r < NR; r++)
-#pragma unroll
-                for (int q = 0; q < SQ_Q; q++) accq[q] += g[r][q] * v[r];
-        }
-        for (; j < M; j++) {
-            const gptr_cc row = G + (size_t)uni(lused[j]) * (size_t)K * 8;
-            const double v0 = lvec[j];
-#pragma unroll
-            for (int q = 0; q < SQ_Q; q++) accq[q] += *(gptr_cd2)(row + off[q]) * v0;
-        }
-#pragma unroll
-        for (int q = 0; q < SQ_Q; q++) {
-            const int i = ib + 2 * (q * nthr + tid);
-            if (i < f1) {
-                gm_sq_apply(W, mode, beta, c1, c2, newrow, i, accq[q][0]);
-                gm_sq_apply(W, mode, beta, c1, c2, newrow, i + 1, accq[q][1]);
-            }
-        }
-    }
-}
-// The vector and the Gram row ids of the M rows of a sweep -> LDS.  A delete whose sweep was held back (gm_inner) runs
-// after its slot shuffle: `del_jj` >= 0 names the freed slot and `del_row` the Gram row that sat there; the row that
-// moved into it goes back to the end of the list.
-DEV void gm_sq_stage(const Blk &B, const GmWork &W, int M, const double *vec, lptr_d lvec, lptr_i lused, int del_jj, int del_row)
-{
-    blk_sync(B);
-    for (int j = B.tid; j < M; j += B.nthr) {
-        lvec[j] = vec[j];
-        int r = W.rowid[j];
-        if (del_jj >= 0) { if (j == del_jj) r = del_row; else if (j == M - 1) r = W.rowid[del_jj]; }
-        lused[j] = r;
-    }
-    blk_sync(B);
-}
-// stage row ids and the vector in LDS, then tiles [t0, t1) of 128 features with one pair per thread
-// (the shape a claimed chunk has: owner and helpers)
-DEV void gm_sq_tiles(const Blk &B, const FoldDev &F, const GmWork &W, int K, int M, const double *vec, int mode, double beta,
-                     double c1, double c2, const double *newrow, int t0, int t1, bool stage, int del_jj = -1, int del_row = -1)
-{
-    const gptr_cc G = (gptr_cc)as_global(uni_ptr(F.G));
-    const lptr_d lvec = as_lds(B.pool);
-    const lptr_i lused = as_lds((int *)(B.pool + ((M + 1) & ~1)));
-    const int tid = B.tid, nthr = uni(B.nthr);
-    if (stage) gm_sq_stage(B, W, M, vec, lvec, lused, del_jj, del_row);
-    const int Kp = K & ~1, f0 = t0 * SQ_FT, f1 = t1 * SQ_FT < Kp ? t1 * SQ_FT : Kp;
-    gm_sq_core<1, 8>(G, lvec, lused, W, uni(K), uni(M), mode, beta, c1, c2, newrow, f0, f1, tid, nthr);
-}
-#endif
-
-// a[i] = sum_j G[used[j], i] * vec[j] for all features, fused with the S_in/Q_in update that
-// consumes it.  `rid`: Gram row id of the new feature (mode 1), else -1.  del_jj / del_row: see gm_sq_stage.
-DEVNI void gm_sq_update(const Blk &B, const FoldDev &F, const GmWork &W, int K, int M, const double *vec,
-                        int mode, double beta, double c1, double c2, int rid, GmScalars &S, int del_jj = -1, int del_row = -1)
-{
-    const double *newrow = rid >= 0 ? F.G + (size_t)rid * K : nullptr;
-    CNT(c.sum_m_swept += M);
-#ifdef PAREBEN_HOST_EMUL
-    PAR(i, K) {
-        double a = 0;
-        for (int j = 0; j < M; j++) {
-            int r = W.rowid[j];
-            if (del_jj >= 0) { if (j == del_jj) r = del_row; else if (j == M - 1) r = W.rowid[del_jj]; }
-            a += F.G[(size_t)r * K + i] * vec[j];
-        }
-        gm_sq_apply(W, mode, beta, c1, c2, newrow, i, a);
-    }
-#else
-    PH_BEGIN();
-    const gptr_cc G = (gptr_cc)as_global(uni_ptr(F.G));
-    const lptr_d lvec = as_lds(B.pool);
-    const lptr_i lused = as_lds((int *)(B.pool + ((M + 1) & ~1)));
-    const int tid = B.tid, nthr = uni(B.nthr);
-    K = uni(K); M = uni(M);
-    gm_sq_stage(B, W, M, vec, lvec, lused, del_jj, del_row);
-    const int Kp = K & ~1;                                    // pairs cover [0, Kp); an odd last feature is handled below
-    const int n_tiles = (Kp + SQ_FT - 1) / SQ_FT;
-    // the job carries (mode, rid | the deleted slot's Gram row, the deleted slot) so that a helper stages the same rows
-    const bool shared = M >= 96 && job_share(B, S, JOB_SQ, M, n_tiles, beta, mode, mode == 2 ? del_row : rid, del_jj, c1, c2, [&](int t0, int t1) {
-        gm_sq_tiles(B, F, W, K, M, vec, mode, beta, c1, c2, newrow, t0, t1, false);
-    });
-    if (!shared) gm_sq_core<5, 2>(G, lvec, lused, W, K, M, mode, beta, c1, c2, newrow, 0, Kp, tid, nthr);
-    if ((K & 1) && tid == 0) {                                // the odd last feature
-        double a = 0;
-        for (int j = 0; j < M; j++) a += *(gptr_cd)(G + ((size_t)lused[j] * (size_t)K + (K - 1)) * 8) * lvec[j];
-        gm_sq_apply(W, mode, beta, c1, c2, newrow, K - 1, a);
-    }
-    PH_END(PH_KSWEEP);
-#endif
-    blk_sync(B);
-}
-
-// Sigma[j][i] += a_j * b_i over the M x M block (the rank-1 update every action ends with), a_j = fa(j),
-// b_i = fb(i).  On the device both vectors are staged in LDS (at `scr`, 2 M doubles) and each wave keeps four
-// column chunks of b in registers while it walks its rows, so the only memory traffic is the coalesced
-// read-modify-write of Sigma with four loads in flight per wave; one fma per element either way.
-template <class FA, class FB>
-DEV void gm_rank1(const Blk &B, const GmWork &W, int M, double *scr, FA fa, FB fb)
-{
-    const int ld = W.ld;
-#ifdef PAREBEN_HOST_EMUL
-    (void)scr;
-    for (int j = 0; j < M; j++) {
-        const double f = fa(j);
-        for (int i = 0; i < M; i++) W.Sig[(size_t)j * ld + i] += f * fb(i);
-    }
-#else
-    const lptr_d la = as_lds(scr), lb = as_lds(scr + M);
-    blk_sync(B);
-    PAR(i, M) { la[i] = fa(i); lb[i] = fb(i); }
-    blk_sync(B);
-    const gptr_d Sg = as_global_rw(W.Sig);
-    const int lane = B.lane, wave = B.wave, nwave = B.nwave;
-    // up to 8 column chunks of 64 per pass (balanced over the passes), two rows per trip: 16 loads in flight
-    const int NC = (M + BLK_LANES - 1) / BLK_LANES, npass = (NC + 7) >> 3, cpp = (NC + npass - 1) / npass;
-    for (int p = 0; p < npass; p++) {
-        const int i0 = p * cpp * BLK_LANES + lane;
-        double br[8];
-#pragma unroll
-        for (int c = 0; c < 8; c++) { const int i = i0 + c * BLK_LANES; br[c] = (c < cpp && i < M) ? lb[i] : 0.0; }
-        for (int j = wave; j < M; j += 2 * nwave) {
-            const int j2 = j + nwave;
-            const bool two = j2 < M;
-            const double f0 = la[j], f1 = two ? la[j2] : 0.0;
-            double s0[8], s1[8];
-#pragma unroll
-            for (int c = 0; c < 8; c++) {
-                const int i = i0 + c * BLK_LANES;
-                const bool on = c < cpp && i < M;
-                s0[c] = on ? Sg[(size_t)j * ld + i] : 0.0;
-                s1[c] = (on && two) ? Sg[(size_t)j2 * ld + i] : 0.0;
-            }
-#pragma unroll
-            for (int c = 0; c < 8; c++) {
-                const int i = i0 + c * BLK_LANES;
-                const bool on = c < cpp && i < M;
-                if (on) Sg[(size_t)j * ld + i] = s0[c] + f0 * br[c];
-                if (on && two) Sg[(size_t)j2 * ld + i] = s1[c] + f1 * br[c];
-            }
-        }
-    }
-#endif
 }
 
 // re-estimate slot jj, MainEff.c:553-596
@@ -920,202 +288,6 @@ DEVNI void gm_reestimate(const Blk &B, const FoldDev &F, const GmWork &W, int K,
     PH_END(PH_RANK1); }
     if (defer) { S.pend.kind = 1; S.pend.M = M; S.pend.beta = S.beta; S.pend.c1 = kappa; S.pend.c2 = mujj; }
     else gm_sq_update(B, F, W, K, M, W.v2, 0, S.beta, kappa, mujj, -1, S);
-}
-
-// Gram row of feature u = the reference's BASIS_PHI row for that basis (MainEff.c:1608-1630):
-// G[i] = x_i . (x_u / scale_u) / scale_i.  Returns the row id r with the row at F.G + r*K, or -1.
-//   full mode (F.lazy == 0): every row was computed by gram_kernel; r = u.
-//   lazy mode: K x K does not fit in HBM.  Rows live in a per-fold pool shared by every workgroup
-//   working on that fold and are computed on first use by sweeping the fold's design once (what
-//   the reference does at every add of every fit).  slot_of[u]: -1 absent, -2 being computed,
-//   >= 0 pool slot, published with an agent-scope release / consumed behind an agent-scope acquire.
-//   A row is written once before it is published and never again, and its values do not depend on
-//   who computed it (fixed summation order), so results stay independent of timing.  A waiting
-//   workgroup waits only for one that is computing (the grid is fully resident and a computing
-//   workgroup never waits); the wait is bounded anyway and falls back to a private copy.
-//   When the pool is exhausted the row goes into one of the workgroup's private rows (released
-//   again at delete / end of fit): the reference's own per-fit BASIS_PHI, one design sweep per add.
-#ifdef PAREBEN_HOST_EMUL
-DEV double wave_sum(double v) { return v; }
-#define ROW_LOAD(p) (*(p))
-#define ROW_CAS(p, e, d) (*(p) == (e) ? (*(p) = (d), true) : ((e) = *(p), false))
-#define ROW_STORE(p, v) (*(p) = (v))
-#define ROW_FETCH_ADD(p, v) ((*(p) += (v)) - (v))
-#else
-#define ROW_LOAD(p) __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define ROW_CAS(p, e, d) __hip_atomic_compare_exchange_strong(p, &(e), d, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define ROW_STORE(p, v) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define ROW_FETCH_ADD(p, v) __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#endif
-#define ROW_SPIN_MAX 400000       // x ~1 us: far beyond one row sweep
-DEVNI int gm_row(const Blk &B, const FoldDev &F, const GmWork &W, int K, int u)
-{
-    if (!F.lazy) return u;
-    enum { R_OWNER = -3, R_PRIVATE = -4 };
-    blk_sync(B);
-    if (B.tid == 0) {
-        int *st = F.slot_of + u;
-        int s = ROW_LOAD(st);
-        if (s == -1) {
-            int expect = -1;
-            if (ROW_CAS(st, expect, -2)) s = R_OWNER; else s = expect;
-        }
-#ifndef PAREBEN_HOST_EMUL
-        for (int spin = 0; s == -2 && spin < ROW_SPIN_MAX; spin++) {
-            __builtin_amdgcn_s_sleep(32);
-            s = ROW_LOAD(st);
-        }
-#endif
-        if (s == -2 || s == -1) s = R_PRIVATE;                  // timed out / the owner found the pool full
-        int my = -1;
-        if (s == R_OWNER) {
-            if (ROW_LOAD(F.pool_next) < F.pool_rows) my = ROW_FETCH_ADD(F.pool_next, 1);
-            if (my >= 0 && my < F.pool_rows) my += F.pool_base;
-            else { my = -1; ROW_STORE(st, -1); s = R_PRIVATE; }    // pool exhausted
-        }
-        if (s == R_PRIVATE && W.pfree[0] > 0) my = W.pfree[W.pfree[0]--];   // one of this fit's own rows
-        B.ired[0] = s;
-        B.ired[1] = my;
-#ifndef PAREBEN_HOST_EMUL
-        if (s >= 0) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-#endif
-    }
-    blk_sync(B);
-    const int s = B.ired[0], my = B.ired[1];
-    blk_sync(B);
-    if (s >= 0) return s;
-    if (my < 0) return -1;
-    const int N = F.N;
-    double *row = const_cast<double *>(F.G) + (size_t)my * K;
-    const double *xu = F.X + (size_t)u * N;
-    // PHI as the reference forms it: a main-effect column times the reciprocal of its norm (:517-520), a pair column divided by it (Full2.c:544)
-    const double su = u < F.n_main ? 1.0 : F.scale[u], ru = u < F.n_main ? F.rscale[u] : 1.0;
-    const bool in_lds = N <= B.pool_n;
-    if (in_lds) {
-        PAR(h, N) B.pool[h] = xu[h] * ru / su;                  // one of the two factors is exactly 1
-        blk_sync(B);
-    }
-#ifdef PAREBEN_HOST_EMUL
-    for (int i = B.wave; i < K; i += B.nwave) {
-        const double *xi = F.X + (size_t)i * N;
-        double a = 0;
-        for (int h = B.lane; h < N; h += BLK_LANES) a += xi[h] * (xu[h] * ru / su);
-        if (B.lane == 0) row[i] = a / F.scale[i];
-    }
-#else
-    // eight features per wave and reduction tree (wave_sum8 pairs lanes exactly like wave_sum: same bits)
-    for (int i0 = B.wave * 8; i0 < K; i0 += B.nwave * 8) {
-        double a[8];
-#pragma unroll
-        for (int c = 0; c < 8; c++) {
-            const double *xi = F.X + (size_t)(i0 + c < K ? i0 + c : K - 1) * N;
-            double t = 0;
-            if (in_lds) for (int h = B.lane; h < N; h += BLK_LANES) t += xi[h] * B.pool[h];
-            else for (int h = B.lane; h < N; h += BLK_LANES) t += xi[h] * (xu[h] * ru / su);
-            a[c] = t;
-        }
-        wave_sum8(a, B.lane);
-        const int i = i0 + (B.lane >> 3);
-        if ((B.lane & 7) == 0 && i < K) row[i] = a[0] / F.scale[i];
-    }
-#endif
-#ifndef PAREBEN_HOST_EMUL
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its stores
-#endif
-    blk_sync(B);
-    if (s == R_OWNER && B.tid == 0) {
-#ifndef PAREBEN_HOST_EMUL
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-        ROW_STORE(F.slot_of + u, my);
-    }
-    blk_sync(B);
-    return my;
-}
-
-// out[i] = sum_j Sigma[i][j] v[j], j ascending, one fma chain per row (the reference's loop order, so the
-// bits do not depend on how the work is laid out).  A thread per row reading its own row would touch 64
-// cache lines per wave-load; instead each wave takes 64 rows and moves them CW columns at a time through a
-// private LDS tile: coalesced 16-byte loads (CW/2 lanes per row), transposed by the tile (pitch CW+1,
-// conflict-free), then every lane walks its own row out of LDS.  The next chunk's loads are in flight while
-// the current one is summed.  scr: (M rounded up to 16) + nwave * 64 * (CW+1) doubles of LDS.
-#define MV_LDS(M, nwave, CW) ((((M) + 15) & ~15) + (nwave) * 64 * ((CW) + 1))
-template <int CW>
-DEV void gm_sigma_matvec(const Blk &B, const GmWork &W, int M, const double *v, double *out, double *scr, int scr_n, lptr_d out_lds)
-{
-    const int ld = W.ld;
-#ifdef PAREBEN_HOST_EMUL
-    (void)scr; (void)scr_n; (void)out_lds;
-    PAR(i, M) {
-        double a = 0;
-        for (int j = 0; j < M; j++) a += W.Sig[(size_t)i * ld + j] * v[j];
-        out[i] = a;
-    }
-#else
-    if (MV_LDS(M, B.nwave, CW) > scr_n) {                       // no room for the tiles: a thread per row
-        PAR(i, M) {
-            double a = 0;
-            for (int j = 0; j < M; j++) a += W.Sig[(size_t)i * ld + j] * v[j];
-            out[i] = a;
-            if (out_lds) out_lds[i] = a;
-        }
-        return;
-    }
-    typedef double d2 __attribute__((ext_vector_type(2)));
-    typedef const d2 __attribute__((address_space(1))) *gptr_cd2;
-    constexpr int LPR = CW / 2, RPI = 64 / LPR, NI = 64 / RPI, TP = CW + 1;
-    const int lane = B.lane, wave = B.wave, nwave = B.nwave;
-    const lptr_d lv = as_lds(scr);
-    const lptr_d tile = lv + ((M + 15) & ~15) + wave * 64 * TP;
-    blk_sync(B);
-    PAR(j, M) lv[j] = v[j];
-    blk_sync(B);
-    const gptr_cd Sg = as_global(W.Sig);
-    const int lr = lane / LPR, lc = (lane % LPR) * 2;
-    for (int r0 = wave * 64; r0 < M; r0 += nwave * 64) {
-        size_t rowoff[NI];
-#pragma unroll
-        for (int q = 0; q < NI; q++) { int r = r0 + q * RPI + lr; if (r > M - 1) r = M - 1; rowoff[q] = (size_t)r * ld + lc; }
-        d2 nx[NI];
-#pragma unroll
-        for (int q = 0; q < NI; q++) nx[q] = *(gptr_cd2)(Sg + rowoff[q]);
-        double a = 0;
-        for (int j0 = 0; j0 < M; j0 += CW) {
-            d2 cur[NI];
-#pragma unroll
-            for (int q = 0; q < NI; q++) cur[q] = nx[q];
-            if (j0 + CW < M) {
-#pragma unroll
-                for (int q = 0; q < NI; q++) nx[q] = *(gptr_cd2)(Sg + rowoff[q] + j0 + CW);
-            }
-#pragma unroll
-            for (int q = 0; q < NI; q++) {
-                tile[(q * RPI + lr) * TP + lc] = cur[q][0];
-                tile[(q * RPI + lr) * TP + lc + 1] = cur[q][1];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0): the tile is written
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (j0 + CW <= M) {
-#pragma unroll
-                for (int c = 0; c < CW; c++) a += tile[lane * TP + c] * lv[j0 + c];
-            } else {
-#pragma unroll
-                for (int c = 0; c < CW; c++) if (j0 + c < M) a += tile[lane * TP + c] * lv[j0 + c];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_s_waitcnt(0xC07F);                 // the tile is consumed before it is overwritten
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
-        if (r0 + lane < M) { out[r0 + lane] = a; if (out_lds) out_lds[r0 + lane] = a; }
-    }
-#endif
 }
 
 // add feature nu, MainEff.c:1585-1723 + :613-627
@@ -1149,288 +321,12 @@ DEVNI void gm_add(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScal
         W.rowid[M] = rid;
         W.upos[nu] = M;
     }
-#ifndef PAREBEN_HOST_EMUL
-    if (S.gc_ok) {                                            // the new slot's column of the Gram block cache
-        const gptr_cd G = as_global(F.G);
-        PAR(j, M) W.Gc[(size_t)j * ld + M] = G[(size_t)W.rowid[j] * K + nu];
-        if (B.tid == 0) W.Gc[(size_t)M * ld + M] = G[(size_t)rid * K + nu];
-    }
-#endif
+    gm_gc_add(B, F, W, K, S, M, nu, rid);                      // the new slot's column of the Gram block cache (gm_dev.h)
     if (defer) { S.pend.kind = 2; S.pend.M = M; S.pend.beta = beta; S.pend.c1 = sii; S.pend.c2 = mui; S.pend.row = rid; }
     else gm_sq_update(B, F, W, K, M, W.v2, 1, beta, sii, mui, rid, S);
     GM_TRACE("    add nu=%d newA=%.15g sii=%.15g mui=%.15g tp0=%.15g tmp0=%.15g Sin=%.15g Qin=%.15g mu0=%.15g\n", nu, newA, sii, mui, W.v2[0], W.v1[0], W.Sin[nu], W.Qin[nu], W.mu[0]);
     S.M = M + 1;
 }
-
-#ifndef PAREBEN_HOST_EMUL
-// Lazy Gram mode: rows of several features in ONE sweep of the fold's design (gm_row does one row per
-// sweep; a run of T adds needs T of them).  For every feature of `nus` that nobody has computed or is
-// computing, this workgroup claims the row (same protocol as gm_row), takes a pool slot, then sweeps the
-// design once with all claimed features' columns staged in LDS -- each design column is loaded once and
-// dotted with every staged column (same lane assignment and reduction as gm_row: identical values) --
-// and publishes the rows.  Anything it cannot claim (already there, in flight elsewhere, pool full) is
-// simply left to the gm_row calls that follow.
-#define ROWS_MAX 16
-DEVNI void gm_rows_prefetch(const Blk &B, const FoldDev &F, int K, const int *nus, int T)
-{
-    if (!F.lazy || T < 2) return;
-    const int N = F.N;
-    int cmax = B.pool_n / (N > 0 ? N : 1);                      // staged columns that fit in the LDS pool
-    if (cmax > ROWS_MAX) cmax = ROWS_MAX;
-    if (cmax < 2) return;
-    const lptr_i lfeat = as_lds(B.ired + 2 * BLK_MAX_WAVES), lslot = as_lds(B.ired + 2 * BLK_MAX_WAVES + ROWS_MAX);
-    blk_sync(B);
-    if (B.tid == 0) {
-        int c = 0;
-        for (int t = 0; t < T && c < cmax; t++) {
-            int *st = F.slot_of + nus[t];
-            int expect = -1;
-            if (ROW_LOAD(st) != -1 || !ROW_CAS(st, expect, -2)) continue;            // present or in flight: not ours
-            int my = -1;
-            if (ROW_LOAD(F.pool_next) < F.pool_rows) my = ROW_FETCH_ADD(F.pool_next, 1);
-            if (my < 0 || my >= F.pool_rows) { ROW_STORE(st, -1); break; }           // pool exhausted: leave it to gm_row
-            lfeat[c] = nus[t]; lslot[c] = my + F.pool_base; c++;
-        }
-        B.ired[0] = c;
-    }
-    blk_sync(B);
-    const int C = B.ired[0];
-    blk_sync(B);
-    if (C == 0) return;
-    for (int c = 0; c < C; c++) {
-        const double *xu = F.X + (size_t)lfeat[c] * N;
-        const bool mainc = lfeat[c] < F.n_main;
-        const double su = mainc ? 1.0 : F.scale[lfeat[c]], ru = mainc ? F.rscale[lfeat[c]] : 1.0;
-        PAR(h, N) B.pool[c * N + h] = xu[h] * ru / su;
-    }
-    blk_sync(B);
-    double *Gw = const_cast<double *>(F.G);
-    for (int i = B.wave; i < K; i += B.nwave) {
-        const double *xi = F.X + (size_t)i * N;
-        double a[ROWS_MAX];
-#pragma unroll
-        for (int c = 0; c < ROWS_MAX; c++) a[c] = 0;
-        for (int h = B.lane; h < N; h += BLK_LANES) {
-            const double x = xi[h];
-#pragma unroll
-            for (int c = 0; c < ROWS_MAX; c++) if (c < C) a[c] += x * B.pool[c * N + h];
-        }
-        const double sc = F.scale[i];
-#pragma unroll
-        for (int c0 = 0; c0 < ROWS_MAX; c0 += 8) {              // eight staged columns per reduction tree
-            if (c0 < C) {
-                double v[8];
-#pragma unroll
-                for (int c = 0; c < 8; c++) v[c] = a[c0 + c];
-                wave_sum8(v, B.lane);
-                const int c = c0 + (B.lane >> 3);
-                if ((B.lane & 7) == 0 && c < C) Gw[(size_t)lslot[c] * K + i] = v[0] / sc;
-            }
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains its stores
-    blk_sync(B);
-    if (B.tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        for (int c = 0; c < C; c++) ROW_STORE(F.slot_of + lfeat[c], lslot[c]);
-    }
-    blk_sync(B);
-}
-
-// S_in / Q_in update of one feature by one add (gm_sq_apply mode 1), with the products spelled out so
-// that the K-space sweep and the M-space tracking below round identically.
-DEV void gm_add_apply(double &sin, double &qin, double beta, double rowval, double a, double sii, double mui)
-{
-    const double mc = beta * rowval - beta * a;
-    sin = sin - mc * mc * sii;
-    qin = qin - mui * mc;
-}
-
-// The K-space half of a run of T consecutive adds: ONE sweep over the Gram rows of the (final) active
-// set instead of T.  For add t (active-set size M0 + t when it is applied, vector vb[t]) feature i needs
-// a_t[i] = sum_{j < M0+t} G[row_j][i] vb[t][j]; the vectors are staged zero-padded in LDS, so every thread
-// loads each row element once and feeds TT accumulators; the new features' own rows (the rows M0 .. M0+T-1
-// of the sweep) are picked up on the way.  Then the T updates are applied in order.  TT = T rounded up.
-template <int TT>
-DEV void gm_sq_batch(const Blk &B, const FoldDev &F, const GmWork &W, int K, int M0, int T, double beta, int f0, int f1)
-{
-    typedef double d2 __attribute__((ext_vector_type(2), aligned(8)));
-    typedef const d2 __attribute__((address_space(1))) *gptr_cd2;
-    const gptr_cc G = (gptr_cc)as_global(uni_ptr(F.G));
-    const int tid = B.tid, nthr = uni(B.nthr);
-    const int Mt = M0 + T;                                      // rows of the sweep
-    const int ldv = W.cap + 2;
-    const lptr_d lvb = as_lds(B.pool);                          // [TT][Mt] zero-padded vectors
-    const lptr_d lsc = as_lds(B.pool + TT * Mt);                // sii[TT], mui[TT]
-    const lptr_i lused = as_lds((int *)(B.pool + TT * Mt + 2 * TT));
-    blk_sync(B);
-    for (int e = tid; e < TT * Mt; e += nthr) {
-        const int t = e / Mt, j = e - t * Mt;
-        lvb[e] = (t < T && j < M0 + t) ? W.vb[(size_t)t * ldv + j] : 0.0;
-    }
-    for (int t = tid; t < TT; t += nthr) { lsc[t] = t < T ? W.bsc[t] : 0.0; lsc[TT + t] = t < T ? W.bsc[ADD_TB + t] : 0.0; }
-    for (int j = tid; j < Mt; j += nthr) lused[j] = W.rowid[j];
-    blk_sync(B);
-    K = uni(K);
-    const int Kp = f1;                                          // features [f0, f1), both even, f1 <= K & ~1
-    for (int ib = f0; ib < Kp; ib += 2 * nthr) {
-        const int i = ib + 2 * tid;
-        const unsigned off = (unsigned)((i < Kp ? i : Kp - 2) * 8);
-        d2 acc[TT], rowv[TT];
-#pragma unroll
-        for (int t = 0; t < TT; t++) { acc[t] = d2{0, 0}; rowv[t] = d2{0, 0}; }
-        int j = 0;
-        for (; j + 1 < M0; j += 2) {                            // rows of the old active set, two per trip
-            const d2 g0 = *(gptr_cd2)(G + (size_t)uni(lused[j]) * (size_t)K * 8 + off);
-            const d2 g1 = *(gptr_cd2)(G + (size_t)uni(lused[j + 1]) * (size_t)K * 8 + off);
-#pragma unroll
-            for (int t = 0; t < TT; t++) { acc[t] += g0 * lvb[t * Mt + j]; acc[t] += g1 * lvb[t * Mt + j + 1]; }
-        }
-        if (j < M0) {
-            const d2 g0 = *(gptr_cd2)(G + (size_t)uni(lused[j]) * (size_t)K * 8 + off);
-#pragma unroll
-            for (int t = 0; t < TT; t++) acc[t] += g0 * lvb[t * Mt + j];
-        }
-#pragma unroll
-        for (int s2 = 0; s2 < TT; s2++) {                       // the new features' own rows: row M0+s2 feeds the adds after s2
-            if (s2 < T) {
-                const d2 g = *(gptr_cd2)(G + (size_t)uni(lused[M0 + s2]) * (size_t)K * 8 + off);
-                rowv[s2] = g;
-#pragma unroll
-                for (int t = s2 + 1; t < TT; t++) acc[t] += g * lvb[t * Mt + M0 + s2];
-            }
-        }
-        if (i < Kp) {
-            double s0 = W.Sin[i], q0 = W.Qin[i], s1 = W.Sin[i + 1], q1 = W.Qin[i + 1];
-#pragma unroll
-            for (int t = 0; t < TT; t++) {
-                if (t < T) {
-                    gm_add_apply(s0, q0, beta, rowv[t][0], acc[t][0], lsc[t], lsc[TT + t]);
-                    gm_add_apply(s1, q1, beta, rowv[t][1], acc[t][1], lsc[t], lsc[TT + t]);
-                }
-            }
-            W.Sin[i] = s0; W.Qin[i] = q0; W.Sin[i + 1] = s1; W.Qin[i + 1] = q1;
-        }
-    }
-    blk_sync(B);
-}
-
-// features [f0, f1) of the sweep of a run of T adds (the owner's whole range, or a claimed chunk of it)
-DEV void gm_sq_batch_range(const Blk &B, const FoldDev &F, const GmWork &W, int K, int M0, int T, double beta, int f0, int f1)
-{
-    if (T <= 4) gm_sq_batch<4>(B, F, W, K, M0, T, beta, f0, f1);
-    else if (T <= 8) gm_sq_batch<8>(B, F, W, K, M0, T, beta, f0, f1);
-    else gm_sq_batch<ADD_TB>(B, F, W, K, M0, T, beta, f0, f1);
-}
-
-// the whole sweep: shared with idle workgroups when the job board is open (same arithmetic per feature
-// whoever runs it), the odd last feature by the owner
-DEVNI void gm_sq_batch_all(const Blk &B, const FoldDev &F, const GmWork &W, int K, int M0, int T, double beta, GmScalars &S)
-{
-    CNT(c.sum_m_swept += M0 + T);                               // one sweep of the final active set's rows for the whole run
-    const int Kp = K & ~1;
-    const int n_tiles = (Kp + SQ_FT - 1) / SQ_FT;
-    const bool shared = M0 + T >= 96 && job_share(B, S, JOB_SQB, M0, n_tiles, beta, T, -1, -1, 0.0, 0.0, [&](int t0, int t1) {
-        gm_sq_batch_range(B, F, W, K, M0, T, beta, t0 * SQ_FT, t1 * SQ_FT < Kp ? t1 * SQ_FT : Kp);
-    });
-    if (!shared) gm_sq_batch_range(B, F, W, K, M0, T, beta, 0, Kp);
-    if ((K & 1) && B.tid == 0) {                                // the odd last feature
-        const int i = K - 1, ldv = W.cap + 2;
-        double s0 = W.Sin[i], q0 = W.Qin[i];
-        for (int t = 0; t < T; t++) {
-            double a = 0;
-            for (int j = 0; j < M0 + t; j++) a += F.G[(size_t)W.rowid[j] * K + i] * W.vb[(size_t)t * ldv + j];
-            gm_add_apply(s0, q0, beta, F.G[(size_t)W.rowid[M0 + t] * K + i], a, W.bsc[t], W.bsc[ADD_TB + t]);
-        }
-        W.Sin[i] = s0; W.Qin[i] = q0;
-    }
-    blk_sync(B);
-}
-
-// A run of T (2 .. ADD_TB) consecutive ADD actions of one block update = gm_add applied T times
-// (MainEff.c:1585-1723 + :613-627), restructured: the M-space part of every add (Sigma border, mu) runs in
-// sequence as before, but the K-space part -- each add's sweep over all Gram rows, which is what an action
-// costs -- is deferred and done for the whole run in ONE sweep (gm_sq_batch).  The only K-space values the
-// M-space part needs in between are S_in / Q_in of the run's own features (sii, mui of the later adds):
-// those T values are tracked on the side with the same arithmetic (one lane per feature, rows in order).
-// W.rowid[M0 .. M0+T) must already hold the Gram row ids of the run's features.
-DEVNI void gm_add_batch(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScalars &S, const int *nus, int T, bool defer)
-{
-    const int M0 = S.M, ld = W.ld, ldv = W.cap + 2, Mt = M0 + T;
-    const double beta = S.beta;
-    double *sii_v = W.bsc, *mui_v = W.bsc + ADD_TB, *sin_v = W.bsc + 2 * ADD_TB, *qin_v = W.bsc + 3 * ADD_TB;
-    // LDS: gb[u][j] = G[row_j][nus[u]], the Gram values of the run's own features at every row of the final
-    // active set (gathered once, in parallel; the side tracking below then runs out of LDS), the current
-    // add's vector, and the scratch of the rank-1 update.
-    const lptr_d gb = as_lds(B.pool), lv2 = gb + (size_t)T * Mt;
-    double *scr = B.pool + (size_t)T * Mt + Mt;
-    const lptr_i lrow = as_lds((int *)scr);
-    const gptr_cd G = as_global(F.G);
-    blk_sync(B);
-    if (B.tid < T) { sin_v[B.tid] = W.Sin[nus[B.tid]]; qin_v[B.tid] = W.Qin[nus[B.tid]]; }
-    PAR(j, Mt) lrow[j] = W.rowid[j];
-    blk_sync(B);
-    for (int e = B.tid; e < T * Mt; e += B.nthr) {
-        const int u = e / Mt, j = e - u * Mt;
-        gb[e] = G[(size_t)lrow[j] * K + nus[u]];
-    }
-    blk_sync(B);
-    for (int t = 0; t < T; t++) {
-        const int M = M0 + t, nu = nus[t], rid = W.rowid[M];
-        const double newA = W.aroot[nu];
-        const double *row = F.G + (size_t)rid * K;
-        double *v2 = W.vb + (size_t)t * ldv;
-        PAR(l, M) W.v1[l] = beta * row[W.used[l]];
-        blk_sync(B);
-        { PH_BEGIN();
-        gm_sigma_matvec<8>(B, W, M, W.v1, v2, scr, B.pool_n - T * Mt - Mt, lv2);
-        PH_END(PH_MATVEC); }
-        const double sii = 1.0 / (newA + sin_v[t]);
-        const double mui = sii * qin_v[t];
-        blk_sync(B);
-        PAR(i, M) W.mu[i] += -mui * v2[i];
-        // S_in / Q_in of the run's later features after this add: lane 0 of wave (u - t - 1) mod nwave walks
-        // the rows in order (the same fma chain as the sweep in gm_sq_batch), operands from LDS
-        { PH_BEGIN();
-        for (int u = t + 1 + B.wave; u < T; u += B.nwave) {
-            if (B.lane == 0) {
-                const lptr_d gu = gb + (size_t)u * Mt;
-                double a = 0;
-#pragma unroll 8
-                for (int j = 0; j < M; j++) a += gu[j] * lv2[j];
-                gm_add_apply(sin_v[u], qin_v[u], beta, gu[M], a, sii, mui);
-            }
-        }
-        PH_END(PH_TRACK); }
-        { PH_BEGIN();
-        gm_rank1(B, W, M, scr, [&](int j) { return sii * v2[j]; }, [&](int i) { return v2[i]; });
-        PH_END(PH_RANK1); }
-        PAR(i, M) {
-            const double si = -sii * v2[i];
-            W.Sig[(size_t)M * ld + i] = si;
-            W.Sig[(size_t)i * ld + M] = si;
-        }
-        if (B.tid == 0) {
-            W.Sig[(size_t)M * ld + M] = sii;
-            W.A[M] = newA;
-            W.mu[M] = mui;
-            W.used[M] = nu;
-            W.upos[nu] = M;
-            sii_v[t] = sii; mui_v[t] = mui;
-        }
-        if (S.gc_ok) PAR(j, M + 1) W.Gc[(size_t)j * ld + M] = gb[(size_t)t * Mt + j];   // the new slot's column of the Gram block cache
-        blk_sync(B);
-    }
-    if (defer) { S.pend.kind = 4; S.pend.M = M0; S.pend.T = T; S.pend.beta = beta; }
-    else {
-        PH_BEGIN();
-        gm_sq_batch_all(B, F, W, K, M0, T, beta, S);
-        PH_END(PH_KSWEEP);
-    }
-    S.M = M0 + T;
-}
-#endif
 
 // the K-space half a block's last unit left in S.pend (gm_inner)
 DEV void gm_flush_pending(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScalars &S)
@@ -1440,9 +336,7 @@ DEV void gm_flush_pending(const Blk &B, const FoldDev &F, const GmWork &W, int K
     if (p.kind == 1) gm_sq_update(B, F, W, K, p.M, W.v2, 0, p.beta, p.c1, p.c2, -1, S);
     else if (p.kind == 2) gm_sq_update(B, F, W, K, p.M, W.v2, 1, p.beta, p.c1, p.c2, p.row, S);
     else if (p.kind == 3) gm_sq_update(B, F, W, K, p.M, W.v2, 2, p.beta, p.c1, p.c2, -1, S, p.jj, p.row);
-#ifndef PAREBEN_HOST_EMUL
-    else if (p.kind == 4) { PH_BEGIN(); gm_sq_batch_all(B, F, W, K, p.M, p.T, p.beta, S); PH_END(PH_KSWEEP); }
-#endif
+    else if (p.kind == 4) gm_flush_add_run(B, F, W, K, S, p.M, p.T, p.beta);
 }
 
 // delete slot jj, MainEff.c:1725-1822 + :640-651.  `nu` is the feature the action named; it
@@ -1490,377 +384,25 @@ DEVNI void gm_delete(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmS
     blk_sync(B);
 }
 
-// Sigma <- H^-1 for the SPD M x M matrix held in Sig (in place, Gauss-Jordan without pivoting:
-// the pivots are the Cholesky pivots squared, so a non-positive pivot means "not SPD").
-// Stands in for dpotrf+dpotri (:1346-1369).  Returns 0 on success.
-DEVNI int gm_spd_inverse_scalar(const Blk &B, const GmWork &W, int M)
-{
-    const int ld = W.ld;
-    for (int k = 0; k < M; k++) {
-        PAR(i, M) { W.v3[i] = W.Sig[(size_t)k * ld + i]; W.v4[i] = W.Sig[(size_t)i * ld + k]; }
-        blk_sync(B);
-        const double d = W.v3[k];
-        if (!(d > 0)) return 1;
-        const double rd = 1.0 / d;
-        for (int j = B.wave; j < M; j += B.nwave) {
-            const double rkj = W.v4[j] * rd;
-            for (int i = B.lane; i < M; i += BLK_LANES) {
-                double a;
-                if (i == k) a = (j == k) ? rd : rkj;
-                else if (j == k) a = -W.v3[i] * rd;
-                else a = W.Sig[(size_t)j * ld + i] - W.v3[i] * rkj;
-                W.Sig[(size_t)j * ld + i] = a;
-            }
-        }
-        blk_sync(B);
-    }
-    return 0;
-}
-
-#ifndef PAREBEN_HOST_EMUL
-// Blocked form of the same elimination for the GPU: the symmetric sweep operator applied 16
-// pivots at a time on the lower triangle,
-//     A11 <- -A11^-1,   A21 <- A21 A11^-1,   A22 <- A22 - A21 A11^-1 A21'
-// (after all blocks the matrix holds -H^-1; one last pass negates and mirrors).  The rank-16
-// update of A22 runs on the FP64 matrix cores, one 16 x 16 tile per MFMA group, so the matrix
-// makes M/16 round trips through L2 instead of M.  LDS: Tn = -A21 A11^-1 (M x 16, pitch 18) and
-// the 16 x 16 pivot block.
-#define INV_TP 18
-#ifndef INV_TT
-#define INV_TT 2           // tiles of the trailing update each wave keeps in flight
-#endif
-#ifndef INV_RUN
-#define INV_RUN 4          // tiles per run (multiple of INV_TT)
-#endif
-// TP: where the M x 16 panel Tn lives -- LDS while it fits (M <= 1040 with the 152 KB pool), else the fit's own
-// scratch in HBM (W.Tn, L2-resident: 2048 x 18 doubles = 295 KB); the two 16 x 17 pivot blocks are always in LDS.
-template <class TP>
-DEVNI int gm_spd_inverse_blocked(const Blk &B, const GmWork &W, int M, long long *phx, const TP Tn, const lptr_d nD)
-{
-    const int ld = W.ld;
-    const gptr_d Sig = as_global_rw(W.Sig);
-    const int nT = (M + 15) >> 4, Mp = nT * 16;
-    const lptr_d nD2 = nD + 16 * 17;                         // second copy for the pivot sweeps
-    const int l15 = B.lane & 15, l4 = B.lane >> 4;
-    for (int tk = 0; tk < nT; tk++) {
-        const int k0 = tk * 16;
-        __syncthreads();
-        PHX_BEGIN(t_piv);
-        if (B.tid < 256) {                                   // pivot block (identity-padded)
-            const int r = B.tid & 15, c = B.tid >> 4, gi = k0 + r, gj = k0 + c;
-            double v;
-            if (gi < M && gj < M) { const int hi = gi > gj ? gi : gj, lo = gi > gj ? gj : gi; v = Sig[(size_t)lo * ld + hi]; }
-            else v = (gi == gj) ? 1.0 : 0.0;
-            nD[r * 17 + c] = v;
-        }
-        __syncthreads();
-        for (int s = 0; s < 16; s++) {                        // scalar sweeps inside the block, ping-pong between two
-            const lptr_d src = (s & 1) ? nD2 : nD, dst = (s & 1) ? nD : nD2;   // copies: one barrier per sweep
-            const double d = src[s * 17 + s];
-            if (!(d > 0)) return 1;
-            if (B.tid < 256) {
-                const int r = B.tid & 15, c = B.tid >> 4;
-                const double prs = src[r * 17 + s], psc = src[s * 17 + c], v = src[r * 17 + c];
-                double nv;
-                if (r == s && c == s) nv = -1.0 / d;
-                else if (r == s) nv = psc / d;
-                else if (c == s) nv = prs / d;
-                else nv = v - prs * psc / d;
-                dst[r * 17 + c] = nv;
-            }
-            __syncthreads();
-        }                                                     // 16 sweeps: the result is back in nD
-        PHX_END(t_piv, PH_INV_PIVOT);
-        PHX_BEGIN(t_tn);
-        // Tn[i][r] = sum_s A(i, k0+s) * nD[s][r] for rows outside the block (zero inside / padding): one 16 x 16 x 16
-        // product per row tile on the matrix cores (four chained ops = the same k-ascending fma chain a scalar loop
-        // runs, tools/ubench/mfma_f64_order.hip); rows <-> i, columns <-> r
-        for (int ti = B.wave; ti < nT; ti += B.nwave) {
-            const int i = ti * 16 + l15;
-            const bool live = i < M && (i < k0 || i >= k0 + 16);
-            d4 acc = d4{0, 0, 0, 0};
-            double av[4], bw[4];
-#pragma unroll
-            for (int kk = 0; kk < 4; kk++) {
-                const int kc = k0 + kk * 4 + l4;
-                double v = 0;
-                if (live && kc < M) v = (i > kc) ? Sig[(size_t)kc * ld + i] : Sig[(size_t)i * ld + kc];
-                av[kk] = v;
-                bw[kk] = nD[(kk * 4 + l4) * 17 + l15];
-            }
-#pragma unroll
-            for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bw[kk], acc, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; r++) Tn[(size_t)(ti * 16 + l4 + 4 * r) * INV_TP + l15] = acc[r];
-        }
-        __syncthreads();
-        PHX_END(t_tn, PH_INV_TN);
-        // A22 += Tn * A21'  on the lower-triangle tiles that do not touch the pivot block.
-        // MFMA rows <-> j (column of A), MFMA columns <-> i (row of A): stores are contiguous in i.
-        // The tiles form a triangle over the nT - 1 non-pivot tile indices; tile number q = a (a + 1) / 2 + b
-        // (b <= a) goes to wave q mod nwave.  Each wave handles INV_TT of its tiles per trip so that their loads
-        // are in flight together (a tile on its own is one load -> matrix op -> store latency chain).
-        {
-            // The work is cut into runs of up to INV_RUN tiles down one tile column b (same 16 columns j of A,
-            // consecutive row tiles a >= b): the A21' operand depends on b only and is loaded once per run, which
-            // takes a third off the bytes a tile moves -- this phase is bound by the CU's path to L2, not by the
-            // matrix cores.  Runs are dealt to the waves round-robin; INV_TT tiles of a run are in flight together.
-            const int n1 = nT - 1;
-            int cnt = 0;
-            for (int b = 0; b < n1; b++) {
-                const int tj = b < tk ? b : b + 1;                  // skip the pivot tile row / column
-                for (int a0 = b; a0 < n1; a0 += INV_RUN) {
-                    if ((cnt++) % B.nwave != B.wave) continue;
-                    const int a1 = a0 + INV_RUN < n1 ? a0 + INV_RUN : n1;
-                    const int jrow = tj * 16 + l15;
-                    double av[4];
-#pragma unroll
-                    for (int kk = 0; kk < 4; kk++) {
-                        const int kc = k0 + kk * 4 + l4;
-                        double a_ = 0;
-                        if (jrow < M && kc < M) a_ = (jrow > kc) ? Sig[(size_t)kc * ld + jrow] : Sig[(size_t)jrow * ld + kc];
-                        av[kk] = a_;
-                    }
-                    for (int a = a0; a < a1; a += INV_TT) {
-                        d4 acc[INV_TT];
-                        double bv[INV_TT][4];
-#pragma unroll
-                        for (int z = 0; z < INV_TT; z++) {
-                            const int az = a + z < a1 ? a + z : a1 - 1;
-                            const int ti = az < tk ? az : az + 1;
-                            const int icol = ti * 16 + l15;
-#pragma unroll
-                            for (int r = 0; r < 4; r++) {
-                                const int j = tj * 16 + l4 + 4 * r;
-                                acc[z][r] = (icol < M && j < M) ? Sig[(size_t)j * ld + icol] : 0.0;
-                            }
-#pragma unroll
-                            for (int kk = 0; kk < 4; kk++) bv[z][kk] = Tn[(size_t)icol * INV_TP + kk * 4 + l4];
-                        }
-#pragma unroll
-                        for (int z = 0; z < INV_TT; z++)
-#pragma unroll
-                            for (int kk = 0; kk < 4; kk++) acc[z] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[z][kk], acc[z], 0, 0, 0);
-#pragma unroll
-                        for (int z = 0; z < INV_TT; z++) {
-                            if (a + z < a1) {
-                                const int ti = a + z < tk ? a + z : a + z + 1;
-                                const int icol = ti * 16 + l15;
-#pragma unroll
-                                for (int r = 0; r < 4; r++) {
-                                    const int j = tj * 16 + l4 + 4 * r;
-                                    if (icol < M && j < M) Sig[(size_t)j * ld + icol] = acc[z][r];
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        // pivot column panel <- A21 A11^-1 = -Tn, pivot block <- -A11^-1
-        for (int e = B.tid; e < Mp * 16; e += B.nthr) {
-            const int i = e >> 4, r = e & 15, kc = k0 + r;
-            if (i >= M || kc >= M || (i >= k0 && i < k0 + 16)) continue;
-            const double v = -Tn[(size_t)i * INV_TP + r];
-            if (i > kc) Sig[(size_t)kc * ld + i] = v; else Sig[(size_t)i * ld + kc] = v;
-        }
-        if (B.tid < 256) {
-            const int r = B.tid & 15, c = B.tid >> 4;
-            if (k0 + r < M && k0 + c < M) Sig[(size_t)(k0 + c) * ld + k0 + r] = nD[r * 17 + c];
-        }
-    }
-    __syncthreads();
-    for (int j = B.wave; j < M; j += B.nwave)
-        for (int i = j + B.lane; i < M; i += 64) {
-            const double v = -Sig[(size_t)j * ld + i];
-            Sig[(size_t)j * ld + i] = v;
-            Sig[(size_t)i * ld + j] = v;
-        }
-    __syncthreads();
-    return 0;
-}
-#endif
-
-DEV int gm_spd_inverse(const Blk &B, const GmWork &W, int M, long long *phx = nullptr)
-{
-    (void)phx;
-#ifndef PAREBEN_HOST_EMUL
-    const int Mp = ((M + 15) >> 4) * 16;
-    if (M > 16 && Mp * INV_TP + 2 * 16 * 17 <= B.pool_n) {
-        const lptr_d Tn = as_lds(B.pool);
-        return gm_spd_inverse_blocked(B, W, M, phx, Tn, Tn + (size_t)Mp * INV_TP);
-    }
-    if (M > 16 && W.Tn) return gm_spd_inverse_blocked(B, W, M, phx, as_global_rw(W.Tn), as_lds(B.pool));
-#endif
-    return gm_spd_inverse_scalar(B, W, M);
-}
-
 // H = beta Phi'Phi + diag(A); Sigma = H^-1; mu = beta Sigma Phi't.  MainEff.c:1841-1921
 DEVNI int gm_final_update(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScalars &S)
 {
     const int M = S.M, ld = W.ld;
     const double beta = S.beta;
-#ifdef PAREBEN_HOST_EMUL
-    for (int j = 0; j < M; j++) {
-        const int uj = W.used[j];
-        for (int i = 0; i < M; i++) {
-            const int ui = W.used[i];
-            // Phi_i.Phi_j from the Gram matrix; one triangle so that H is exactly symmetric
-            double h = (i <= j ? F.G[(size_t)W.rowid[i] * K + uj] : F.G[(size_t)W.rowid[j] * K + ui]) * beta;
-            if (i == j) h += W.A[i];
-            W.H[(size_t)j * ld + i] = h;
-            W.Sig[(size_t)j * ld + i] = h;
-        }
-    }
-#else
-    {   // feature ids, Gram row ids and A staged in LDS: the M^2 gathers then depend on nothing but LDS
-        PH_BEGIN();
-        int *lu = (int *)B.pool, *lr = lu + M;
-        double *la = B.pool + M + 1;
-        blk_sync(B);
-        PAR(l, M) { lu[l] = W.used[l]; lr[l] = W.rowid[l]; la[l] = W.A[l]; }
-        blk_sync(B);
-        const gptr_cd G = as_global(F.G);
-        const gptr_d H = as_global_rw(W.H), Sg = as_global_rw(W.Sig), Gc = as_global_rw(W.Gc);
-        const bool cached = S.gc_ok != 0;
-        // the blocked inverse reads and writes only the triangle [j][i >= j] (and mirrors Sigma itself at the end);
-        // the scattered mirror stores are needed only in front of the scalar inverse (M <= 16, or no LDS room)
-        const bool mirror = !(M > 16 && (((M + 15) >> 4) * 16 * INV_TP + 2 * 16 * 17 <= B.pool_n || W.Tn));
-        for (int j = B.wave; j < M; j += B.nwave) {
-            const size_t rj = (size_t)lr[j] * K;
-            // Phi_i.Phi_j from the Gram matrix: element (j, i >= j) is G[row_j][used_i] -- gathered from Gram row j
-            // (one row per wave trip, not a column walk across M rows) the first time and after a delete has
-            // reshuffled the slots, otherwise taken from the fit's own copy of that block, which every add extends
-            // by one column (gm_add, gm_add_batch): a coalesced read instead of M^2/2 gathers.  One triangle stands for
-            // both, so H is exactly symmetric.  Four loads are issued before the first store so that they overlap.
-            for (int i0 = j + B.lane; i0 < M; i0 += 4 * BLK_LANES) {
-                double h[4];
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const int i = i0 + c * BLK_LANES;
-                    h[c] = i < M ? (cached ? Gc[(size_t)j * ld + i] : G[rj + lu[i]]) : 0.0;
-                }
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const int i = i0 + c * BLK_LANES;
-                    if (i < M) {
-                        if (!cached) Gc[(size_t)j * ld + i] = h[c];
-                        double v = h[c] * beta;
-                        if (i == j) v += la[i];
-                        H[(size_t)j * ld + i] = v;
-                        Sg[(size_t)j * ld + i] = v;
-                        if (mirror && i != j) { H[(size_t)i * ld + j] = v; Sg[(size_t)i * ld + j] = v; }
-                    }
-                }
-            }
-        }
-        blk_sync(B);
-        S.gc_ok = 1;
-        PH_END(PH_HBUILD);
-    }
-#endif
+    gm_hessian_build(B, F, W, K, S);
     PAR(l, M) W.v1[l] = W.bt[W.used[l]];
     blk_sync(B);
     { PH_BEGIN(); const int bad = gm_spd_inverse(B, W, M, S.ph); PH_END(PH_INVERSE); if (bad) return 1; }
-#ifndef PAREBEN_HOST_EMUL
-    // blocked inverse: per 16-pivot step one panel product per row tile + the triangle of trailing tiles
-    if (M > 16) CNT(const int64_t nT = (M + 15) >> 4; c.mfma_tiles += nT * (nT + (nT - 1) * nT / 2));
-#endif
+    gm_inverse_count(B, S, M);
     PH_BEGIN();
-#ifdef PAREBEN_HOST_EMUL
-    PAR(i, M) {
-        double a = 0;
-        for (int j = 0; j < M; j++) a += W.v1[j] * W.Sig[(size_t)j * ld + i];
-        W.mu[i] = a * beta;
-    }
-#else
-    {   // the vector from LDS, Sigma through a global pointer: the row loads of a thread pipeline
-        const lptr_d lv = as_lds(B.pool);
-        PAR(j, M) lv[j] = W.v1[j];
-        blk_sync(B);
-        const gptr_cd Sg = as_global(W.Sig);
-        PAR(i, M) {
-            double a = 0;
-#pragma unroll 8
-            for (int j = 0; j < M; j++) a += lv[j] * Sg[(size_t)j * ld + i];
-            W.mu[i] = a * beta;
-        }
-    }
-#endif
+    gm_mu_update(B, W, M, beta);
     blk_sync(B);
     PH_END(PH_MU);
     return 0;
 }
 
-// out_h = sum_j vec[j] * (X[used[j]][h] * rscale[used[j]])  for one sample h, the model columns in order.
-// On the device the (column id, coefficient, 1/|x|) triples are staged in LDS first (gm_stage_model), so
-// the only memory access per term is the coalesced design-column load and nothing sits behind a dependent
-// used[] -> rscale[] address chain; the arithmetic is the same expression in the same order either way.
-#ifdef PAREBEN_HOST_EMUL
-DEV void gm_stage_model(const Blk &, const FoldDev &, const GmWork &, int, const double *) {}
-DEV double gm_model_at(const Blk &, const FoldDev &F, const GmWork &W, int M, const double *vec, int N, int h)
-{
-    double v = 0;
-    for (int j = 0; j < M; j++) { const int uj = W.used[j]; v += vec[j] * (F.X[(size_t)uj * N + h] * F.rscale[uj]); }
-    return v;
-}
-#else
-DEV void gm_stage_model(const Blk &B, const FoldDev &F, const GmWork &W, int M, const double *vec)
-{
-    double *lc = B.pool, *lr = B.pool + M;
-    int *lu = (int *)(B.pool + 2 * M);
-    blk_sync(B);
-    PAR(j, M) { const int uj = W.used[j]; lu[j] = uj; lc[j] = vec[j]; lr[j] = F.rscale[uj]; }
-    blk_sync(B);
-}
-DEV double gm_model_at(const Blk &B, const FoldDev &F, const GmWork &, int M, const double *, int N, int h)
-{
-    const lptr_d lc = as_lds(B.pool), lr = as_lds(B.pool + M);
-    const lptr_i lu = as_lds((int *)(B.pool + 2 * M));
-    const gptr_cd X = as_global(F.X);
-    double v = 0;
-#pragma unroll 4
-    for (int j = 0; j < M; j++) v += lc[j] * (X[(size_t)lu[j] * N + h] * lr[j]);
-    return v;
-}
-// two samples at once (twice the design-column loads in flight; each sum is the same chain as above)
-DEV void gm_model_at2(const Blk &B, const FoldDev &F, int M, int N, int h0, int h1, double &v0, double &v1)
-{
-    const lptr_d lc = as_lds(B.pool), lr = as_lds(B.pool + M);
-    const lptr_i lu = as_lds((int *)(B.pool + 2 * M));
-    const gptr_cd X = as_global(F.X);
-    double a0 = 0, a1 = 0;
-#pragma unroll 4
-    for (int j = 0; j < M; j++) {
-        const size_t col = (size_t)lu[j] * N;
-        const double c = lc[j], r = lr[j];
-        a0 += c * (X[col + h0] * r);
-        a1 += c * (X[col + h1] * r);
-    }
-    v0 = a0; v1 = a1;
-}
-#endif
-
 // ---- decision trace (diagnostics only: S.trace is null in every production launch) -------------------------
 DEV unsigned long long gm_dbits(double v) { unsigned long long u; __builtin_memcpy(&u, &v, 8); return u; }
-DEV unsigned long long blk_xor64(const Blk &B, unsigned long long v)
-{
-#ifndef PAREBEN_HOST_EMUL
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v ^= __shfl_xor(v, o, 64);
-    unsigned long long *r = (unsigned long long *)B.red;
-    __syncthreads();
-    if (B.lane == 0) r[B.wave] = v;
-    __syncthreads();
-    v = 0;
-    for (int w = 0; w < B.nwave; w++) v ^= r[w];
-    __syncthreads();
-#else
-    (void)B;
-#endif
-    return v;
-}
 DEV double blk_max(const Blk &B, double v)
 {
     double bv; int bi;
@@ -2004,38 +546,18 @@ DEV int gm_inner(const Blk &B, const FoldDev &F, const GmWork &W, int K, double 
             for (int u = 0; u < n_todo; u++) {
                 nu = W.todo[u];
                 sel = W.act[nu];
-#ifndef PAREBEN_HOST_EMUL
-                if (sel == ACT_ADD) {                             // a run of consecutive adds: one Gram-row sweep for all
-                    int T = 1;
-                    while (u + T < n_todo && T < ADD_TB && W.act[W.todo[u + T]] == ACT_ADD) T++;
-                    if (S.M + T > W.cap) T = W.cap - S.M;       // the add that overflows is left to the single path below
-                    for (;;) {                                    // LDS of the sweep: TT zero-padded vectors of M0 + T
-                        const int TT = T <= 4 ? 4 : (T <= 8 ? 8 : ADD_TB), Mt = S.M + T;
-                        if (T < 2 || (TT * Mt + 2 * TT + (Mt + 1) / 2 + 8 <= B.pool_n && T * Mt + Mt + MV_LDS(Mt, B.nwave, 8) <= B.pool_n)) break;
-                        T--;
-                    }
-                    if (T >= 2) {
-                        gm_rows_prefetch(B, F, K, W.todo + u, T);   // lazy Gram mode: the run's missing rows in one design sweep
-                        bool ok = true;
-                        for (int t = 0; t < T && ok; t++) {
-                            const int rid = gm_row(B, F, W, K, W.todo[u + t]);
-                            if (rid < 0) ok = false;
-                            else if (B.tid == 0) W.rowid[S.M + t] = rid;
-                        }
-                        if (!ok) { S.status |= ST_OVERFLOW | ST_ABORT; return 1; }
-                        CNT(c.n_add += T; c.sum_m_action += (int64_t)T * S.M + (int64_t)T * (T - 1) / 2);
-                        gm_add_batch(B, F, W, K, S, W.todo + u, T, defer_ok && u + T == n_todo);
-                        if (S.M > W.cap_flag) S.status |= ST_OVERFLOW;   // past the reference's basisMax (MainEff.c:605-611): flagged, not stopped
+                if (sel == ACT_ADD) {                             // a run of consecutive adds: one Gram-row sweep for all (gm_dev.h)
+                    const int T = gm_add_run(B, F, W, K, S, u, n_todo, defer_ok);
+                    if (T < 0) return 1;
+                    if (T > 0) {
                         u += T - 1;
                         nu = W.todo[u];
-                        sel = ACT_ADD;
                         any_upd = true;
                         blk_sync(B);
                         CNT(if (S.M > c.m_max) c.m_max = S.M);
                         continue;
                     }
                 }
-#endif
                 const double newA = W.aroot[nu];
                 if (sel == ACT_REEST || sel == ACT_DEL) {
                     const int l = W.upos[nu];
@@ -2091,22 +613,14 @@ DEV int gm_inner(const Blk &B, const FoldDev &F, const GmWork &W, int K, double 
             PH_BEGIN();
             double ee_part = 0;
             gm_stage_model(B, F, W, M, W.mu);
-#ifdef PAREBEN_HOST_EMUL
-            PAR(h, N) {
-                const double pm = gm_model_at(B, F, W, M, W.mu, N, h);
-                const double e = (F.y[h] - S.b) - pm;
-                ee_part += e * e;
-            }
-#else
             for (int h = B.tid; h < N; h += 2 * B.nthr) {     // a thread's samples in the same order, two per trip
                 const int h2 = h + B.nthr;
                 double pm0, pm1;
-                gm_model_at2(B, F, M, N, h, h2 < N ? h2 : h, pm0, pm1);
+                gm_model_at2(B, F, W, M, W.mu, N, h, h2 < N ? h2 : h, pm0, pm1);
                 const double e0 = (F.y[h] - S.b) - pm0;
                 ee_part += e0 * e0;
                 if (h2 < N) { const double e1 = (F.y[h2] - S.b) - pm1; ee_part += e1 * e1; }
             }
-#endif
             const double ee = blk_sum(B, ee_part);
             double g_part = 0;
             PAR(i, M) g_part += W.gam[i];
@@ -2143,24 +657,15 @@ DEV int gm_inner(const Blk &B, const FoldDev &F, const GmWork &W, int K, double 
         const double beta = S.beta, b2 = beta * beta;
         double a_part = 0, b_part = 0;
         gm_stage_model(B, F, W, M, W.v2);
-#ifdef PAREBEN_HOST_EMUL
-        PAR(h, N) {
-            const double v = gm_model_at(B, F, W, M, W.v2, N, h);
-            const double c = beta - b2 * v;
-            a_part += c;
-            b_part += c * F.y[h];
-        }
-#else
         for (int h = B.tid; h < N; h += 2 * B.nthr) {
             const int h2 = h + B.nthr;
             double v0, v1;
-            gm_model_at2(B, F, M, N, h, h2 < N ? h2 : h, v0, v1);
+            gm_model_at2(B, F, W, M, W.v2, N, h, h2 < N ? h2 : h, v0, v1);
             const double c0 = beta - b2 * v0;
             a_part += c0;
             b_part += c0 * F.y[h];
             if (h2 < N) { const double c1 = beta - b2 * v1; a_part += c1; b_part += c1 * F.y[h2]; }
         }
-#endif
         *cs = blk_sum(B, a_part);
         *csy = blk_sum(B, b_part);
     }

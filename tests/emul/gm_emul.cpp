@@ -3,6 +3,8 @@
 // that tests can compare its control flow and results with the oracle without a GPU.  The
 // shipped library never links this and has no CPU fallback.
 #define PAREBEN_HOST_EMUL 1
+#define GM_PHASES_H "../../tests/emul/gm_host.h"      // plain-loop phases instead of pareben_amd/csrc/gm_dev.h (paths relative to gm_fit.h)
+#define BM_PHASES_H "../../tests/emul/bm_host.h"      // same for the binomial fit (bm_dev.h)
 #include <vector>
 #include <cmath>
 #include <cstring>

@@ -15,7 +15,8 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        deps = [_SRC] + [os.path.join(_HERE, "..", "pareben_amd", "csrc", f) for f in ("gm_fit.h", "bm_fit.h", "blk.h", "types.h")]
+        deps = [_SRC, os.path.join(_HERE, "emul", "gm_host.h"), os.path.join(_HERE, "emul", "bm_host.h")] + \
+               [os.path.join(_HERE, "..", "pareben_amd", "csrc", f) for f in ("gm_fit.h", "bm_fit.h", "blk.h", "types.h")]
         if not os.path.exists(_SO) or any(os.path.getmtime(d) > os.path.getmtime(_SO) for d in deps):
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", _SO, _SRC])
         _lib = C.CDLL(_SO)
