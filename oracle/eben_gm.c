@@ -518,7 +518,9 @@ static int gm_inner(gm *s, int iter, double residual, double varY, double *cs, d
             uint64_t hs = 0, hq = 0, hg = 0;
             for (int i = 0; i < K; i++) { hs ^= dbits(s->Sin[i]); hq ^= dbits(s->Qin[i]); }
             for (int j = 0; j < s->M; j++) { hg ^= dbits(s->mu[j]); for (int i = 0; i < s->M; i++) hg ^= dbits(s->Sig[(size_t)j * s->M + i]); }
-            tr[TR_SEL] = (uint64_t)(int64_t)sel; tr[TR_MAFTER] = s->M; tr[TR_BETA] = dbits(s->beta);
+            uint32_t hu = 0;                         /* order-free hash of the active set: which features, not only how many */
+            for (int j = 0; j < s->M; j++) hu += (uint32_t)(s->used[j] + 1) * 2654435761u;
+            tr[TR_SEL] = (uint64_t)(int64_t)sel; tr[TR_MAFTER] = (uint64_t)s->M | ((uint64_t)hu << 32); tr[TR_BETA] = dbits(s->beta);
             tr[TR_HSIN] = hs; tr[TR_HQIN] = hq; tr[TR_HSIG] = hg;
             g_trace[0]++;
         }

@@ -257,14 +257,19 @@ DEVNI int bm_delta_ml(const Blk &B, const BmWork &W, int K, int N, int NU, doubl
         rescanned = true;
     }
     blk_sync(B);
+    // ties: the reference's first scan walks the used list in slot order, then the unused one, and keeps the first strict
+    // maximum (an active feature wins over an inactive one at bit-equal dML: see gm_delta_ml); a rescan runs in index order
     double v = 0; int idx = 0x7fffffff;
     PAR(i, K) {
-        if (!rescanned && W.upos[i] == UP_LOST) continue;
+        const int l = W.upos[i];
+        if (!rescanned && l == UP_LOST) continue;
         const double d = W.dml[i];
-        if (d > v) { v = d; idx = i; }
+        const int key = rescanned ? i : (l >= 0 ? l : NU + i);
+        if (d > v || (d == v && d > 0 && key < idx)) { v = d; idx = key; }
     }
     double bv; int bi;
     blk_argmax(B, v, idx, &bv, &bi);
+    if (!rescanned && bv > 0) bi = bi < NU ? W.used[bi] : bi - NU;
     if (!(bv > 0)) { bv = 0; bi = 0; }
     *best = bv;
     return bi;

