@@ -19,6 +19,7 @@
 #include <string.h>
 #include "eben_oracle.h"
 #include "eben_linalg.h"
+#include "eben_lapack38.h"
 #ifdef EBEN_TRACE
 #include <stdio.h>
 #define TRACE(...) fprintf(stderr, __VA_ARGS__)
@@ -374,7 +375,14 @@ static void gm_final_update(gm *s)
             s->H[(size_t)j * M + i] = dot_seq(N, s->Phi + (size_t)i * N, s->Phi + (size_t)j * N) * s->beta;
     for (int i = 0; i < M; i++) s->H[(size_t)i * M + i] += s->A[i];
     memcpy(s->Sig, s->H, sizeof(double) * M * M);
-    if (chol_inverse_upper(s->Sig, M)) s->c.status |= 2;   /* Q11: carry on regardless */
+    /* dpotrf + dpotri: the unblocked netlib restatement (eben_linalg.h) by default.  EBEN_ORACLE_LAPACK38=1 switches to the
+     * blocked LAPACK 3.8.0 algorithms (NB = 64, recursive dpotrf2; eben_lapack38.h) -- a hypothesis about real R's build that
+     * was tested on the stored tables and moves no chaotic fit back onto R */
+    {
+        static int blocked = -1;
+        if (blocked < 0) { const char *e = getenv("EBEN_ORACLE_LAPACK38"); blocked = (e && atoi(e)) ? 1 : 0; }
+        if (blocked ? chol_inverse_upper_lapack38(s->Sig, M) : chol_inverse_upper(s->Sig, M)) s->c.status |= 2;   /* Q11: carry on regardless */
+    }
     double *pt = (double *)calloc(M, sizeof(double));
     for (int l = 0; l < M; l++) pt[l] = dot_seq(N, s->Phi + (size_t)l * N, s->t);
     for (int i = 0; i < M; i++) s->mu[i] = 0;

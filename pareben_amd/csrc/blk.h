@@ -11,6 +11,11 @@
 #include <stdint.h>
 #include <math.h>
 
+// Reference parameters of the fit routines (Blk, the workspace and fold descriptors, the scalars) are marked NOALIAS: a non-inlined
+// routine receives them as pointers to the caller's stack, and without the no-alias promise every store through any other
+// pointer forces the fields (thread id, workspace pointers ...) to be loaded again -- inside loops, each time with a full wait.
+#define NOALIAS __restrict__
+
 #ifdef PAREBEN_HOST_EMUL
 #define DEV static inline
 #define DEVNI static

@@ -12,7 +12,7 @@
 #endif
 
 // pm[h] = sum_p Phi_p[h] * mu[p]
-DEVNI void bm_phi_mu(const Blk &B, const FoldDev &F, const BmWork &W, int M, const double *mu, double *out)
+DEVNI void bm_phi_mu(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const BmWork &NOALIAS W, int M, const double *mu, double *out)
 {
     const int N = F.N;
     if (3 * M + 8 <= B.pool_n) {
@@ -93,7 +93,7 @@ DEV void bm_wr_tile(gptr_cd xa, lptr_d zb, lptr_d lw, int pitch, int Nu, int Nr,
 // want_stats (device build): also bb_i = x_i' diag(w) x_i -> W.bb[i] and ze_i = x_i' e -> W.aroot[i] (what the
 // full-stat pass needs per feature, NEmainEff.c:1745-1757), taken from the same pass over the design columns.
 // Returns 1 when it did (matrix-core path), 0 when the caller has to compute them.
-DEVNI int bm_weighted_rows(const Blk &B, const FoldDev &F, const BmWork &W, int K, int M, bool want_stats = false, long long *phx = nullptr)
+DEVNI int bm_weighted_rows(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const BmWork &NOALIAS W, int K, int M, bool want_stats = false, long long *phx = nullptr)
 {
     (void)phx;
     const int N = F.N, ld = W.ld;
@@ -254,7 +254,7 @@ DEVNI int bm_weighted_rows(const Blk &B, const FoldDev &F, const BmWork &W, int 
 // lane l holds BP[feature l & 15][k0 + (l >> 4)], B operand Sigma[k0 + (l >> 4)][16 ct + (l & 15)], 64 columns of Sigma
 // per round), folded with BP on the fly: D register r of lane l is T[feature (l >> 4) + 4 r][column l & 15], multiplied
 // by the same BP entry and summed over the 16 lanes of a row group.
-DEVNI void bm_quad_features(const Blk &B, const FoldDev &F, const BmWork &W, int K, int M)
+DEVNI void bm_quad_features(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const BmWork &NOALIAS W, int K, int M)
 {
     typedef double bd4 __attribute__((ext_vector_type(4)));
     const int ld = W.ld, l15 = B.lane & 15, l4 = B.lane >> 4;
@@ -307,7 +307,7 @@ DEVNI void bm_quad_features(const Blk &B, const FoldDev &F, const BmWork &W, int
 }
 
 // gradient entries 1 .. M-1 and the Hessian Phi' diag(w) Phi + diag(A) of one Newton step (NEmainEff.c:1890-1925)
-DEV void bm_grad_hessian(const Blk &B, const FoldDev &F, const BmWork &W, int M, int N)
+DEV void bm_grad_hessian(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const BmWork &NOALIAS W, int M, int N)
 {
     const int ld = W.ld;
         for (int j = 1 + B.wave; j < M; j += B.nwave) {
@@ -387,7 +387,7 @@ DEV void bm_grad_hessian(const Blk &B, const FoldDev &F, const BmWork &W, int M,
 }
 
 // bb_i = x_i' diag(w) x_i and ze_i = x_i' e for every feature, when bm_weighted_rows did not deliver them
-DEV void bm_feature_stats(const Blk &B, const FoldDev &F, const BmWork &W, int K, int N, int have_stats)
+DEV void bm_feature_stats(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const BmWork &NOALIAS W, int K, int N, int have_stats)
 {
     if (!have_stats) {
         for (int i = B.wave; i < K; i += B.nwave) {
@@ -401,7 +401,7 @@ DEV void bm_feature_stats(const Blk &B, const FoldDev &F, const BmWork &W, int K
 }
 
 // bb[i] = x_i' (w .* phi) / |x_i| for all features and tmp[p] = Phi_p' (w .* phi) for the model columns (bm_add)
-DEV void bm_add_products(const Blk &B, const FoldDev &F, const BmWork &W, int K, int M, int N)
+DEV void bm_add_products(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const BmWork &NOALIAS W, int K, int M, int N)
 {
     // eight features per wave and reduction tree: their loads are in flight together (a feature at a time paid a memory
     // round trip per feature); wave_sum8 pairs lanes exactly like wave_sum, so the sums are the same bits

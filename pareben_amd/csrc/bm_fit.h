@@ -50,7 +50,7 @@ struct BmWork {
 };
 
 // design column u, normalised, at sample h: NEmainEff.c:644-646 multiplies by the reciprocal norm, NeFull.c:437-450 divides
-DEV double bm_col(const FoldDev &F, const BmWork &W, int N, int u, int h)
+DEV double bm_col(const FoldDev &NOALIAS F, const BmWork &NOALIAS W, int N, int u, int h)
 {
     const double x = F.X[(size_t)u * N + h];
     return W.phi_div ? x / F.scale[u] : x * F.rscale[u];
@@ -59,7 +59,7 @@ DEV double bm_col(const FoldDev &F, const BmWork &W, int N, int u, int h)
 #define BM_PHI(p, h) ((p) == 0 ? 1.0 : bm_col(F, W, N, W.used[(p) - 1], (h)))
 
 // a GmWork view so the Gaussian kernel's SPD inverse can be reused on (Sig, ld)
-DEV GmWork bm_as_gm(const BmWork &W)
+DEV GmWork bm_as_gm(const BmWork &NOALIAS W)
 {
     GmWork G{};
     G.Sig = W.Sig; G.H = W.H; G.v3 = W.v3; G.v4 = W.v4; G.cap = W.cap; G.ld = W.ld;
@@ -67,7 +67,7 @@ DEV GmWork bm_as_gm(const BmWork &W)
 }
 
 // pm[h] = sum_p Phi_p[h] * mu[p], every term through BM_PHI
-DEVNI void bm_phi_mu_plain(const Blk &B, const FoldDev &F, const BmWork &W, int M, const double *mu, double *out)
+DEVNI void bm_phi_mu_plain(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const BmWork &NOALIAS W, int M, const double *mu, double *out)
 {
     const int N = F.N;
     PAR(h, N) {
@@ -79,7 +79,7 @@ DEVNI void bm_phi_mu_plain(const Blk &B, const FoldDev &F, const BmWork &W, int 
 }
 
 // y = sigmoid(pm); returns -sum t log y + (1-t) log(1-y)  (:2013-2032)
-DEVNI double bm_data_error(const Blk &B, const FoldDev &F, const BmWork &W)
+DEVNI double bm_data_error(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const BmWork &NOALIAS W)
 {
     const int N = F.N;
     double part = 0;
@@ -103,7 +103,7 @@ DEVNI double bm_data_error(const Blk &B, const FoldDev &F, const BmWork &W)
 #include BM_PHASES_H
 
 // posterior mode, :1808-2010.  Leaves w, Sig (= H^-1), H from its last Hessian evaluation.
-DEVNI int bm_postmode(const Blk &B, const FoldDev &F, const BmWork &W, GmScalars &S)
+DEVNI int bm_postmode(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const BmWork &NOALIAS W, GmScalars &NOALIAS S)
 {
     const int N = F.N, M = S.M, ld = W.ld;
     const double step_min = 1.0 / 256.0;
@@ -173,7 +173,7 @@ DEVNI int bm_postmode(const Blk &B, const FoldDev &F, const BmWork &W, GmScalars
 }
 
 // full statistics, :1633-1803
-DEVNI int bm_fullstat(const Blk &B, const FoldDev &F, const BmWork &W, int K, GmScalars &S)
+DEVNI int bm_fullstat(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const BmWork &NOALIAS W, int K, GmScalars &NOALIAS S)
 {
     const int N = F.N, ld = W.ld;
     S.bp_ok = 0;                                               // the weights change: cached weighted rows are stale
@@ -204,7 +204,7 @@ DEVNI int bm_fullstat(const Blk &B, const FoldDev &F, const BmWork &W, int K, Gm
 }
 
 // dML / action choice, :2063-2238 (Q15: only delete-priority can fire)
-DEVNI int bm_delta_ml(const Blk &B, const BmWork &W, int K, int N, int NU, double lambda, double alpha,
+DEVNI int bm_delta_ml(const Blk &NOALIAS B, const BmWork &NOALIAS W, int K, int N, int NU, double lambda, double alpha,
                       int epis, int *any_del_out, double *best)
 {
     const double l1 = lambda * alpha, l2 = lambda * (1 - alpha);
@@ -275,7 +275,7 @@ DEVNI int bm_delta_ml(const Blk &B, const BmWork &W, int K, int N, int NU, doubl
     return bi;
 }
 
-DEVNI int bm_collect(const Blk &B, const BmWork &W, int K, double cutoff)
+DEVNI int bm_collect(const Blk &NOALIAS B, const BmWork &NOALIAS W, int K, double cutoff)
 {
     int base = 0;
     for (int i0 = 0; i0 < K; i0 += B.nthr) {
@@ -291,7 +291,7 @@ DEVNI int bm_collect(const Blk &B, const BmWork &W, int K, double cutoff)
 }
 
 // add feature nu, :830-1003 + :701-711
-DEVNI void bm_add(const Blk &B, const FoldDev &F, const BmWork &W, int K, GmScalars &S, int nu, double newA)
+DEVNI void bm_add(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const BmWork &NOALIAS W, int K, GmScalars &NOALIAS S, int nu, double newA)
 {
     const int N = F.N, M = S.M, ld = W.ld, NU = M - 1;
     PAR(h, N) W.bphi[h] = W.w[h] * bm_col(F, W, N, nu, h);
@@ -342,7 +342,7 @@ DEVNI void bm_add(const Blk &B, const FoldDev &F, const BmWork &W, int K, GmScal
 }
 
 // delete used slot jj (feature nu), :1010-1121 + :728-744
-DEVNI void bm_delete(const Blk &B, const FoldDev &F, const BmWork &W, int K, GmScalars &S, int jj, int nu)
+DEVNI void bm_delete(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const BmWork &NOALIAS W, int K, GmScalars &NOALIAS S, int jj, int nu)
 {
     const int M = S.M, ld = W.ld, last = M - 1, j1 = jj + 1;
     PAR(i, M) W.tp[i] = W.Sig[(size_t)j1 * ld + i];
@@ -387,7 +387,7 @@ DEVNI void bm_delete(const Blk &B, const FoldDev &F, const BmWork &W, int K, GmS
 }
 
 // re-estimate used slot jj, :1127-1203 (S/Q update reads the NEW Sigma row j1)
-DEVNI void bm_reestimate(const Blk &B, const FoldDev &F, const BmWork &W, int K, GmScalars &S, int jj, double newA)
+DEVNI void bm_reestimate(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const BmWork &NOALIAS W, int K, GmScalars &NOALIAS S, int jj, double newA)
 {
     const int M = S.M, ld = W.ld, j1 = jj + 1;
     PAR(i, M) W.tp[i] = W.Sig[(size_t)j1 * ld + i];
@@ -418,8 +418,8 @@ DEVNI void bm_reestimate(const Blk &B, const FoldDev &F, const BmWork &W, int K,
 }
 
 // one call of the inner routine, :397-827.  *loglik = training log-likelihood at exit.
-DEV int bm_inner(const Blk &B, const FoldDev &F, const BmWork &W, int K, double lambda, double alpha,
-                 GmScalars &S, int iter, double *loglik)
+DEV int bm_inner(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const BmWork &NOALIAS W, int K, double lambda, double alpha,
+                 GmScalars &NOALIAS S, int iter, double *loglik)
 {
     const int N = F.N;
     const bool first = iter <= 1;
@@ -537,8 +537,8 @@ DEV int bm_inner(const Blk &B, const FoldDev &F, const BmWork &W, int K, double 
 
 // The whole fit, :236-389.  On return W.mu[0] is the intercept, W.mu[l+1] the weight of used[l]
 // (normalised-column units), S.M the model size incl. the intercept.
-DEV void bm_fit(const Blk &B, const FoldDev &F, const BmWork &W, int K, double lambda, double alpha,
-                GmScalars &S, double *loglik)
+DEV void bm_fit(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const BmWork &NOALIAS W, int K, double lambda, double alpha,
+                GmScalars &NOALIAS S, double *loglik)
 {
     S.status = 0; S.M = 2; S.beta = 0; S.b = 0;
     S.v.n_add = S.v.epis ? 0.99 : 0.90;
@@ -564,7 +564,7 @@ DEV void bm_fit(const Blk &B, const FoldDev &F, const BmWork &W, int K, double l
 }
 
 // fold score, R/GetModelError.R:34-57: mean Bernoulli log-likelihood of the held-out rows
-DEV double bm_fold_loglik(const Blk &B, const FoldDev &F, const BmWork &W, const GmScalars &S)
+DEV double bm_fold_loglik(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const BmWork &NOALIAS W, const GmScalars &NOALIAS S)
 {
     const int nte = F.nte, M = S.M;
     // eta -> exp(eta), with R's clamp applied only when max/min cross the thresholds

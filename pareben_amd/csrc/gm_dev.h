@@ -18,6 +18,15 @@
 #define PHX_BEGIN(v) do {} while (0)
 #define PHX_END(v, k) do {} while (0)
 #endif
+// finer ticks inside the register form of the inverse, on slots the fit kernels use for other things: only in the
+// single-phase diagnostic build (tools/ubench/inverse_rate.py with DIAG_LIB=libpareben_hip_diagprof.so)
+#if defined(PAREBEN_PHASE_TIMERS) && defined(PAREBEN_DIAG)
+#define PHD_BEGIN(v) PHX_BEGIN(v)
+#define PHD_END(v, k) PHX_END(v, k)
+#else
+#define PHD_BEGIN(v) do {} while (0)
+#define PHD_END(v, k) do {} while (0)
+#endif
 
 // address-space-qualified views (global_load / ds_read instead of flat_load) for the hot loops
 typedef const double __attribute__((address_space(1))) *gptr_cd;
@@ -212,7 +221,7 @@ DEV void fs_step(gptr_cc Sig, gptr_cc G, lptr_cull loff, lptr_d lmu, lptr_d acur
 // pipeline over all (feature tile, row-tile pass, k-block) steps: see fs_step for the work split (every wave owns
 // FS_NB column blocks and all row tiles of a pass), the operand paths (Sigma panels staged through LDS once per
 // workgroup and step, Gram operands straight from memory into a register ring) and the symmetric schedule.
-DEVNI void gm_fullstat_features(const Blk &B, const FoldDev &F, const GmWork &W, int K, int M,
+DEVNI void gm_fullstat_features(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const GmWork &NOALIAS W, int K, int M,
                               double beta, int tile0, int tile1)
 {
     // see fs_step.  B lives in memory (reference argument of a non-inlined function): take register
@@ -357,7 +366,7 @@ DEV int fs_claim(FsJob *job, int n_tiles, int chunk)
 // Owner side.  Returns false when sharing is off / not worth it (the caller then does the whole phase);
 // otherwise opens the job, runs work(tile0, tile1) on the chunks it claims itself, waits for the rest.
 template <class Work>
-DEV bool job_share(const Blk &B, GmScalars &S, int kind, int M, int n_tiles, double beta, int mode, int rid, int aux, double c1,
+DEV bool job_share(const Blk &NOALIAS B, GmScalars &NOALIAS S, int kind, int M, int n_tiles, double beta, int mode, int rid, int aux, double c1,
                    double c2, Work work)
 {
     const FsShare *sh = S.share;
@@ -422,7 +431,7 @@ DEV bool job_share(const Blk &B, GmScalars &S, int kind, int M, int n_tiles, dou
 }
 
 // the whole pass: shared with idle workgroups when the job board is open
-DEVNI void gm_fullstat_pass(const Blk &B, const FoldDev &F, const GmWork &W, int K, int M, double beta, GmScalars &S)
+DEVNI void gm_fullstat_pass(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const GmWork &NOALIAS W, int K, int M, double beta, GmScalars &NOALIAS S)
 {
     const int n_tiles = (K + FS_FT - 1) / FS_FT;
     if (M >= 48 && job_share(B, S, JOB_FULLSTAT, M, n_tiles, beta, 0, -1, -1, 0.0, 0.0,
@@ -430,7 +439,7 @@ DEVNI void gm_fullstat_pass(const Blk &B, const FoldDev &F, const GmWork &W, int
     gm_fullstat_features(B, F, W, K, M, beta, 0, n_tiles);
 }
 // the band between the active block and the next multiple of 16 (see fs_step): exact zeros for the matrix-core pass
-DEV void gm_fs_pad(const Blk &B, const GmWork &W, int M)
+DEV void gm_fs_pad(const Blk &NOALIAS B, const GmWork &NOALIAS W, int M)
 {
     const int ld = W.ld, Mp = ((M + 15) >> 4) << 4, pad = Mp - M;
     for (int e = B.tid; e < Mp * pad; e += B.nthr) {
@@ -440,7 +449,7 @@ DEV void gm_fs_pad(const Blk &B, const GmWork &W, int M)
     }
 }
 // matrix-core work of a pass: per 16-feature block the triangle of (row tile J, k-block h <= J) tile products
-DEV void gm_fs_count(const Blk &B, GmScalars &S, int K, int M)
+DEV void gm_fs_count(const Blk &NOALIAS B, GmScalars &NOALIAS S, int K, int M)
 {
     CNT(const int64_t nJ = (M + 15) >> 4; c.mfma_tiles += (int64_t)((K + FS_FT - 1) / FS_FT) * (FS_FT / 16) * (nJ * (nJ + 1) / 2));
 }
@@ -458,7 +467,7 @@ DEV void gm_fs_count(const Blk &B, GmScalars &S, int K, int M)
 // SQ_Q * NR independent coalesced 1 KB row segments per wave are in flight.  The sum of a feature runs
 // over the rows in order whatever SQ_Q / NR are.
 template <int SQ_Q, int NR>
-DEV void gm_sq_core(gptr_cc G, lptr_d lvec, lptr_i lused, const GmWork &W, int K, int M, int mode, double beta, double c1,
+DEV void gm_sq_core(gptr_cc G, lptr_d lvec, lptr_i lused, const GmWork &NOALIAS W, int K, int M, int mode, double beta, double c1,
                     double c2, const double *newrow, int f0, int f1, int tid, int nthr)
 {
     typedef double d2 __attribute__((ext_vector_type(2), aligned(8)));   // rows of an odd-K matrix start 8 bytes off
@@ -507,7 +516,7 @@ DEV void gm_sq_core(gptr_cc G, lptr_d lvec, lptr_i lused, const GmWork &W, int K
 // The vector and the Gram row ids of the M rows of a sweep -> LDS.  A delete whose sweep was held back (gm_inner) runs
 // after its slot shuffle: `del_jj` >= 0 names the freed slot and `del_row` the Gram row that sat there; the row that
 // moved into it goes back to the end of the list.
-DEV void gm_sq_stage(const Blk &B, const GmWork &W, int M, const double *vec, lptr_d lvec, lptr_i lused, int del_jj, int del_row)
+DEV void gm_sq_stage(const Blk &NOALIAS B, const GmWork &NOALIAS W, int M, const double *vec, lptr_d lvec, lptr_i lused, int del_jj, int del_row)
 {
     blk_sync(B);
     for (int j = B.tid; j < M; j += B.nthr) {
@@ -520,7 +529,7 @@ DEV void gm_sq_stage(const Blk &B, const GmWork &W, int M, const double *vec, lp
 }
 // stage row ids and the vector in LDS, then tiles [t0, t1) of 128 features with one pair per thread
 // (the shape a claimed chunk has: owner and helpers)
-DEV void gm_sq_tiles(const Blk &B, const FoldDev &F, const GmWork &W, int K, int M, const double *vec, int mode, double beta,
+DEV void gm_sq_tiles(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const GmWork &NOALIAS W, int K, int M, const double *vec, int mode, double beta,
                      double c1, double c2, const double *newrow, int t0, int t1, bool stage, int del_jj = -1, int del_row = -1)
 {
     const gptr_cc G = (gptr_cc)as_global(uni_ptr(F.G));
@@ -534,8 +543,8 @@ DEV void gm_sq_tiles(const Blk &B, const FoldDev &F, const GmWork &W, int K, int
 
 // a[i] = sum_j G[used[j], i] * vec[j] for all features, fused with the S_in/Q_in update that
 // consumes it.  `rid`: Gram row id of the new feature (mode 1), else -1.  del_jj / del_row: see gm_sq_stage.
-DEVNI void gm_sq_update(const Blk &B, const FoldDev &F, const GmWork &W, int K, int M, const double *vec,
-                        int mode, double beta, double c1, double c2, int rid, GmScalars &S, int del_jj = -1, int del_row = -1)
+DEVNI void gm_sq_update(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const GmWork &NOALIAS W, int K, int M, const double *vec,
+                        int mode, double beta, double c1, double c2, int rid, GmScalars &NOALIAS S, int del_jj = -1, int del_row = -1)
 {
     const double *newrow = rid >= 0 ? F.G + (size_t)rid * K : nullptr;
     CNT(c.sum_m_swept += M);
@@ -567,7 +576,7 @@ DEVNI void gm_sq_update(const Blk &B, const FoldDev &F, const GmWork &W, int K, 
 // column chunks of b in registers while it walks its rows, so the only memory traffic is the coalesced
 // read-modify-write of Sigma with four loads in flight per wave; one fma per element either way.
 template <class FA, class FB>
-DEV void gm_rank1(const Blk &B, const GmWork &W, int M, double *scr, FA fa, FB fb)
+DEV void gm_rank1(const Blk &NOALIAS B, const GmWork &NOALIAS W, int M, double *scr, FA fa, FB fb)
 {
     const int ld = W.ld;
     const lptr_d la = as_lds(scr), lb = as_lds(scr + M);
@@ -624,7 +633,7 @@ DEV void gm_rank1(const Blk &B, const GmWork &W, int M, double *scr, FA fa, FB f
 #define ROW_STORE(p, v) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define ROW_FETCH_ADD(p, v) __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define ROW_SPIN_MAX 400000       // x ~1 us: far beyond one row sweep
-DEVNI int gm_row(const Blk &B, const FoldDev &F, const GmWork &W, int K, int u)
+DEVNI int gm_row(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const GmWork &NOALIAS W, int K, int u)
 {
     if (!F.lazy) return u;
     enum { R_OWNER = -3, R_PRIVATE = -4 };
@@ -704,7 +713,7 @@ DEVNI int gm_row(const Blk &B, const FoldDev &F, const GmWork &W, int K, int u)
 // the current one is summed.  scr: (M rounded up to 16) + nwave * 64 * (CW+1) doubles of LDS.
 #define MV_LDS(M, nwave, CW) ((((M) + 15) & ~15) + (nwave) * 64 * ((CW) + 1))
 template <int CW>
-DEV void gm_sigma_matvec(const Blk &B, const GmWork &W, int M, const double *v, double *out, double *scr, int scr_n, lptr_d out_lds)
+DEV void gm_sigma_matvec(const Blk &NOALIAS B, const GmWork &NOALIAS W, int M, const double *v, double *out, double *scr, int scr_n, lptr_d out_lds)
 {
     const int ld = W.ld;
     if (MV_LDS(M, B.nwave, CW) > scr_n) {                       // no room for the tiles: a thread per row
@@ -769,7 +778,7 @@ DEV void gm_sigma_matvec(const Blk &B, const GmWork &W, int M, const double *v, 
 }
 
 // the new slot's column of the fit's copy of the Gram block (gm_hessian_build reads it)
-DEV void gm_gc_add(const Blk &B, const FoldDev &F, const GmWork &W, int K, const GmScalars &S, int M, int nu, int rid)
+DEV void gm_gc_add(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const GmWork &NOALIAS W, int K, const GmScalars &NOALIAS S, int M, int nu, int rid)
 {
     const int ld = W.ld;
     if (S.gc_ok) {
@@ -787,7 +796,7 @@ DEV void gm_gc_add(const Blk &B, const FoldDev &F, const GmWork &W, int K, const
 // and publishes the rows.  Anything it cannot claim (already there, in flight elsewhere, pool full) is
 // simply left to the gm_row calls that follow.
 #define ROWS_MAX 16
-DEVNI void gm_rows_prefetch(const Blk &B, const FoldDev &F, int K, const int *nus, int T)
+DEVNI void gm_rows_prefetch(const Blk &NOALIAS B, const FoldDev &NOALIAS F, int K, const int *nus, int T)
 {
     if (!F.lazy || T < 2) return;
     const int N = F.N;
@@ -869,7 +878,7 @@ DEV void gm_add_apply(double &sin, double &qin, double beta, double rowval, doub
 // loads each row element once and feeds TT accumulators; the new features' own rows (the rows M0 .. M0+T-1
 // of the sweep) are picked up on the way.  Then the T updates are applied in order.  TT = T rounded up.
 template <int TT>
-DEV void gm_sq_batch(const Blk &B, const FoldDev &F, const GmWork &W, int K, int M0, int T, double beta, int f0, int f1)
+DEV void gm_sq_batch(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const GmWork &NOALIAS W, int K, int M0, int T, double beta, int f0, int f1)
 {
     typedef double d2 __attribute__((ext_vector_type(2), aligned(8)));
     typedef const d2 __attribute__((address_space(1))) *gptr_cd2;
@@ -933,7 +942,7 @@ DEV void gm_sq_batch(const Blk &B, const FoldDev &F, const GmWork &W, int K, int
 }
 
 // features [f0, f1) of the sweep of a run of T adds (the owner's whole range, or a claimed chunk of it)
-DEV void gm_sq_batch_range(const Blk &B, const FoldDev &F, const GmWork &W, int K, int M0, int T, double beta, int f0, int f1)
+DEV void gm_sq_batch_range(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const GmWork &NOALIAS W, int K, int M0, int T, double beta, int f0, int f1)
 {
     if (T <= 4) gm_sq_batch<4>(B, F, W, K, M0, T, beta, f0, f1);
     else if (T <= 8) gm_sq_batch<8>(B, F, W, K, M0, T, beta, f0, f1);
@@ -942,7 +951,7 @@ DEV void gm_sq_batch_range(const Blk &B, const FoldDev &F, const GmWork &W, int 
 
 // the whole sweep: shared with idle workgroups when the job board is open (same arithmetic per feature
 // whoever runs it), the odd last feature by the owner
-DEVNI void gm_sq_batch_all(const Blk &B, const FoldDev &F, const GmWork &W, int K, int M0, int T, double beta, GmScalars &S)
+DEVNI void gm_sq_batch_all(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const GmWork &NOALIAS W, int K, int M0, int T, double beta, GmScalars &NOALIAS S)
 {
     CNT(c.sum_m_swept += M0 + T);                               // one sweep of the final active set's rows for the whole run
     const int Kp = K & ~1;
@@ -971,7 +980,7 @@ DEVNI void gm_sq_batch_all(const Blk &B, const FoldDev &F, const GmWork &W, int 
 // M-space part needs in between are S_in / Q_in of the run's own features (sii, mui of the later adds):
 // those T values are tracked on the side with the same arithmetic (one lane per feature, rows in order).
 // W.rowid[M0 .. M0+T) must already hold the Gram row ids of the run's features.
-DEVNI void gm_add_batch(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScalars &S, const int *nus, int T, bool defer)
+DEVNI void gm_add_batch(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const GmWork &NOALIAS W, int K, GmScalars &NOALIAS S, const int *nus, int T, bool defer)
 {
     const int M0 = S.M, ld = W.ld, ldv = W.cap + 2, Mt = M0 + T;
     const double beta = S.beta;
@@ -1049,7 +1058,7 @@ DEVNI void gm_add_batch(const Blk &B, const FoldDev &F, const GmWork &W, int K, 
 
 // A run of consecutive adds at todo[u ..]: one Gram-row sweep for all of them (gm_add_batch).  Returns the number of adds
 // applied (0: no run here, the caller takes the single-action path; -1: the fit must stop, status set).
-DEV int gm_add_run(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScalars &S, int u, int n_todo, bool defer_ok)
+DEV int gm_add_run(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const GmWork &NOALIAS W, int K, GmScalars &NOALIAS S, int u, int n_todo, bool defer_ok)
 {
     int T = 1;
     while (u + T < n_todo && T < ADD_TB && W.act[W.todo[u + T]] == ACT_ADD) T++;
@@ -1074,7 +1083,7 @@ DEV int gm_add_run(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmSca
     return T;
 }
 // the held-back sweep of a run of adds (S.pend.kind == 4)
-DEV void gm_flush_add_run(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScalars &S, int M0, int T, double beta)
+DEV void gm_flush_add_run(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const GmWork &NOALIAS W, int K, GmScalars &NOALIAS S, int M0, int T, double beta)
 {
     PH_BEGIN();
     gm_sq_batch_all(B, F, W, K, M0, T, beta, S);
@@ -1098,8 +1107,11 @@ DEV void gm_flush_add_run(const Blk &B, const FoldDev &F, const GmWork &W, int K
 // TP: where the M x 16 panel Tn lives -- LDS while it fits (M <= 1040 with the 152 KB pool), else the fit's own
 // scratch in HBM (W.Tn, L2-resident: 2048 x 18 doubles = 295 KB); the two 16 x 17 pivot blocks are always in LDS.
 template <class TP>
-DEVNI int gm_spd_inverse_blocked(const Blk &B, const GmWork &W, int M, long long *phx, const TP Tn, const lptr_d nD)
+DEVNI int gm_spd_inverse_blocked(const Blk &NOALIAS B_, const GmWork &NOALIAS W, int M, long long *phx, const TP Tn, const lptr_d nD)
 {
+    // B_ is a reference argument of a non-inlined function, i.e. memory: a use inside a loop would be a flat load with its
+    // wait (the sixteen sweeps of a pivot tile each paid one) -- a register copy, taken once
+    const Blk B{B_.tid, uni(B_.nthr), B_.lane, uni(B_.wave), uni(B_.nwave), B_.red, B_.ired, uni_ptr(B_.pool), uni(B_.pool_n)};
     const int ld = W.ld;
     const gptr_d Sig = as_global_rw(W.Sig);
     const int nT = (M + 15) >> 4, Mp = nT * 16;
@@ -1117,21 +1129,23 @@ DEVNI int gm_spd_inverse_blocked(const Blk &B, const GmWork &W, int M, long long
             nD[r * 17 + c] = v;
         }
         __syncthreads();
-        for (int s = 0; s < 16; s++) {                        // scalar sweeps inside the block, ping-pong between two
-            const lptr_d src = (s & 1) ? nD2 : nD, dst = (s & 1) ? nD : nD2;   // copies: one barrier per sweep
-            const double d = src[s * 17 + s];
-            if (!(d > 0)) return 1;
-            if (B.tid < 256) {
-                const int r = B.tid & 15, c = B.tid >> 4;
-                const double prs = src[r * 17 + s], psc = src[s * 17 + c], v = src[r * 17 + c];
-                double nv;
-                if (r == s && c == s) nv = -1.0 / d;
-                else if (r == s) nv = psc / d;
-                else if (c == s) nv = prs / d;
-                else nv = v - prs * psc / d;
-                dst[r * 17 + c] = nv;
+        {   // scalar sweeps inside the block, ping-pong between two copies: one barrier per sweep, one division per
+            // element (numerator chosen first: the operations of the four cases of gm_spd_inverse_scalar); a pivot that
+            // is not positive is noticed by every thread alike and acted upon after the sweeps
+            bool bad = false;
+            const int r = B.tid & 15, c = (B.tid >> 4) & 15;
+#pragma unroll
+            for (int s = 0; s < 16; s++) {
+                const lptr_d src = (s & 1) ? nD2 : nD, dst = (s & 1) ? nD : nD2;
+                const double d = src[s * 17 + s], prs = src[r * 17 + s], psc = src[s * 17 + c], v = src[r * 17 + c];
+                bad |= !(d > 0);
+                const bool rs = r == s, cs = c == s;
+                const double num = rs ? (cs ? -1.0 : psc) : (cs ? prs : prs * psc);
+                const double t = num / d;
+                if (B.tid < 256) dst[r * 17 + c] = (rs || cs) ? t : v - t;
+                __syncthreads();
             }
-            __syncthreads();
+            if (bad) return 1;
         }                                                     // 16 sweeps: the result is back in nD
         PHX_END(t_piv, PH_INV_PIVOT);
         PHX_BEGIN(t_tn);
@@ -1244,10 +1258,471 @@ DEVNI int gm_spd_inverse_blocked(const Blk &B, const GmWork &W, int M, long long
     return 0;
 }
 
-DEV int gm_spd_inverse(const Blk &B, const GmWork &W, int M, long long *phx = nullptr)
+// ---- two pivot blocks per trip through memory ---------------------------------------------------------------
+// The trailing update of the blocked sweep above is bound by the CU's path to L2, not by the matrix cores: a tile is
+// loaded, takes four matrix ops and is stored again, once per pivot block.  Here two consecutive pivot blocks k, k+1
+// share one trip: after block k's panel product only the tiles that block k+1 will read as its pivot block and pivot
+// column (those with tile index k+1: one tile row and one tile column) get block k's update; block k+1's pivot sweeps
+// and panel product follow; then every other tile is loaded ONCE, takes block k's four matrix ops and then block
+// k+1's, and is stored -- the same chain of operations per element as two separate steps (a store and a reload in
+// between change nothing), so the result is bit-identical to gm_spd_inverse_blocked, with half the tile traffic.
+// Operands: both panels Tn (block k, block k+1) in LDS; block k's ORIGINAL pivot column (the A21' operand of its
+// update, overwritten in Sigma before block k+1's panel product needs the new values there) is kept in the fit's
+// HBM scratch Pk[s][i] (16 x Mp, L2-resident), written on the way by block k's panel product.
+DEV int inv_pivot(int tid, const gptr_d Sig, int ld, int M, int k0, const lptr_d nD, const lptr_d nD2)
+{
+    __syncthreads();
+    if (tid < 256) {                                       // pivot block (identity-padded)
+        const int r = tid & 15, c = tid >> 4, gi = k0 + r, gj = k0 + c;
+        double v;
+        if (gi < M && gj < M) { const int hi = gi > gj ? gi : gj, lo = gi > gj ? gj : gi; v = Sig[(size_t)lo * ld + hi]; }
+        else v = (gi == gj) ? 1.0 : 0.0;
+        nD[r * 17 + c] = v;
+    }
+    __syncthreads();
+    // one division per element (numerator chosen first: the same operations as the four cases of the scalar sweep); a pivot
+    // that is not positive is noticed by every thread alike and acted upon after the sweeps
+    bool bad = false;
+    const int r = tid & 15, c = (tid >> 4) & 15;
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+        const lptr_d src = (s & 1) ? nD2 : nD, dst = (s & 1) ? nD : nD2;
+        const double d = src[s * 17 + s], prs = src[r * 17 + s], psc = src[s * 17 + c], v = src[r * 17 + c];
+        bad |= !(d > 0);
+        const bool rs = r == s, cs = c == s;
+        const double num = rs ? (cs ? -1.0 : psc) : (cs ? prs : prs * psc);
+        const double t = num / d;
+        if (tid < 256) dst[r * 17 + c] = (rs || cs) ? t : v - t;
+        __syncthreads();
+    }
+    return bad ? 1 : 0;
+}
+// Tn[i][r] = sum_s A(i, k0+s) nD[s][r] for the rows outside the block (zero inside / padding); SAVE: the operand, i.e.
+// the pivot column as it is now, goes to Pk[s][i] on the way
+template <bool SAVE>
+DEV void inv_panel(const Blk &NOALIAS B, const gptr_d Sig, int ld, int M, int nT, int k0, const lptr_d nD, const lptr_d Tn, const gptr_d Pk, int Mp)
+{
+    const int l15 = B.lane & 15, l4 = B.lane >> 4;
+    for (int ti = B.wave; ti < nT; ti += B.nwave) {
+        const int i = ti * 16 + l15;
+        const bool live = i < M && (i < k0 || i >= k0 + 16);
+        d4 acc = d4{0, 0, 0, 0};
+        double av[4], bw[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            const int kc = k0 + kk * 4 + l4;
+            double v = 0;
+            if (live && kc < M) v = (i > kc) ? Sig[(size_t)kc * ld + i] : Sig[(size_t)i * ld + kc];
+            av[kk] = v;
+            bw[kk] = nD[(kk * 4 + l4) * 17 + l15];
+        }
+        if (SAVE) {
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) Pk[(size_t)(kk * 4 + l4) * Mp + i] = av[kk];
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bw[kk], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) Tn[(size_t)(ti * 16 + l4 + 4 * r) * INV_TP + l15] = acc[r];
+    }
+}
+// pivot column <- A21 A11^-1 = -Tn, pivot block <- -A11^-1
+DEV void inv_write_panel(const Blk &NOALIAS B, const gptr_d Sig, int ld, int M, int Mp, int k0, const lptr_d Tn, const lptr_d nD)
+{
+    for (int e = B.tid; e < Mp * 16; e += B.nthr) {
+        const int i = e >> 4, r = e & 15, kc = k0 + r;
+        if (i >= M || kc >= M || (i >= k0 && i < k0 + 16)) continue;
+        const double v = -Tn[(size_t)i * INV_TP + r];
+        if (i > kc) Sig[(size_t)kc * ld + i] = v; else Sig[(size_t)i * ld + kc] = v;
+    }
+    if (B.tid < 256) {
+        const int r = B.tid & 15, c = B.tid >> 4;
+        if (k0 + r < M && k0 + c < M) Sig[(size_t)(k0 + c) * ld + k0 + r] = nD[r * 17 + c];
+    }
+}
+// the A21' operand of tile column tj for the pivot block at kb, from Sigma (the pivot column as it is now) ...
+DEV void inv_av_sig(const gptr_d Sig, int ld, int M, int tj, int kb, int l15, int l4, double (&av)[4])
+{
+    const int jrow = tj * 16 + l15;
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+        const int kc = kb + kk * 4 + l4;
+        double a_ = 0;
+        if (jrow < M && kc < M) a_ = (jrow > kc) ? Sig[(size_t)kc * ld + jrow] : Sig[(size_t)jrow * ld + kc];
+        av[kk] = a_;
+    }
+}
+// ... or from the saved copy
+DEV void inv_av_pk(const gptr_d Pk, int Mp, int tj, int l15, int l4, double (&av)[4])
+{
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) av[kk] = Pk[(size_t)(kk * 4 + l4) * Mp + tj * 16 + l15];
+}
+// One run of the trailing update: the tiles (ti = rows(a), tj) for a in [a0, a1), INV_TT of them in flight together.
+// NS = 2: A += Tn0 av0' then A += Tn1 av1' (two pivot blocks in one trip); NS = 1: the second pair only.
+template <int NS, class Rows>
+DEV void inv_run(const gptr_d Sig, int ld, int M, int tj, int a0, int a1, Rows rows, const double (&av0)[4], const double (&av1)[4],
+                 const lptr_d Tn0, const lptr_d Tn1, int l15, int l4)
+{
+    for (int a = a0; a < a1; a += INV_TT) {
+        d4 acc[INV_TT];
+        double bv0[INV_TT][4], bv1[INV_TT][4];
+#pragma unroll
+        for (int z = 0; z < INV_TT; z++) {
+            const int ti = rows(a + z < a1 ? a + z : a1 - 1);
+            const int icol = ti * 16 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int j = tj * 16 + l4 + 4 * r;
+                acc[z][r] = (icol < M && j < M) ? Sig[(size_t)j * ld + icol] : 0.0;
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                if (NS == 2) bv0[z][kk] = Tn0[(size_t)icol * INV_TP + kk * 4 + l4];
+                bv1[z][kk] = Tn1[(size_t)icol * INV_TP + kk * 4 + l4];
+            }
+        }
+        if (NS == 2) {
+#pragma unroll
+            for (int z = 0; z < INV_TT; z++)
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) acc[z] = __builtin_amdgcn_mfma_f64_16x16x4f64(av0[kk], bv0[z][kk], acc[z], 0, 0, 0);
+        }
+#pragma unroll
+        for (int z = 0; z < INV_TT; z++)
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) acc[z] = __builtin_amdgcn_mfma_f64_16x16x4f64(av1[kk], bv1[z][kk], acc[z], 0, 0, 0);
+#pragma unroll
+        for (int z = 0; z < INV_TT; z++) {
+            if (a + z < a1) {
+                const int icol = rows(a + z) * 16 + l15;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int j = tj * 16 + l4 + 4 * r;
+                    if (icol < M && j < M) Sig[(size_t)j * ld + icol] = acc[z][r];
+                }
+            }
+        }
+    }
+}
+DEVNI int gm_spd_inverse_paired(const Blk &NOALIAS B_, const GmWork &NOALIAS W, int M, long long *phx)
+{
+    // B_ is a reference argument of a non-inlined function, i.e. memory: a use inside a loop would be a flat load with its
+    // wait (the sixteen sweeps of a pivot tile each paid one) -- a register copy, taken once
+    const Blk B{B_.tid, uni(B_.nthr), B_.lane, uni(B_.wave), uni(B_.nwave), B_.red, B_.ired, uni_ptr(B_.pool), uni(B_.pool_n)};
+    const int ld = W.ld;
+    const gptr_d Sig = as_global_rw(W.Sig), Pk = as_global_rw(W.Tn);
+    const int nT = (M + 15) >> 4, Mp = nT * 16;
+    const lptr_d Tn0 = as_lds(B.pool), Tn1 = Tn0 + (size_t)Mp * INV_TP, nD = Tn1 + (size_t)Mp * INV_TP, nD2 = nD + 16 * 17;
+    const int l15 = B.lane & 15, l4 = B.lane >> 4;
+    const double zero4[4] = {0, 0, 0, 0};
+    int tk = 0;
+    for (; tk + 1 < nT; tk += 2) {
+        const int k0 = tk * 16, k1 = k0 + 16, t1 = tk + 1;
+        // ---- block k: pivot sweeps, panel product (the pivot column saved on the way)
+        PHX_BEGIN(t_piv);
+        if (inv_pivot(B.tid, Sig, ld, M, k0, nD, nD2)) return 1;
+        PHX_END(t_piv, PH_INV_PIVOT);
+        PHX_BEGIN(t_tn);
+        inv_panel<true>(B, Sig, ld, M, nT, k0, nD, Tn0, Pk, Mp);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // Pk: every storing wave drains its stores
+        __syncthreads();
+        PHX_END(t_tn, PH_INV_TN);
+        // ---- block k's update of the tiles block k+1 reads: tile column t1 (rows t1 ..) and tile row t1 (columns < tk)
+        {
+            int cnt = 0;
+            for (int a0 = t1; a0 < nT; a0 += INV_RUN) {
+                if ((cnt++) % B.nwave != B.wave) continue;
+                double av[4];
+                inv_av_pk(Pk, Mp, t1, l15, l4, av);
+                inv_run<1>(Sig, ld, M, t1, a0, a0 + INV_RUN < nT ? a0 + INV_RUN : nT, [](int a) { return a; }, zero4, av, Tn0, Tn0, l15, l4);
+            }
+            for (int b = 0; b < tk; b++) {
+                if ((cnt++) % B.nwave != B.wave) continue;
+                double av[4];
+                inv_av_pk(Pk, Mp, b, l15, l4, av);
+                inv_run<1>(Sig, ld, M, b, t1, t1 + 1, [](int a) { return a; }, zero4, av, Tn0, Tn0, l15, l4);
+            }
+        }
+        __syncthreads();
+        inv_write_panel(B, Sig, ld, M, Mp, k0, Tn0, nD);
+        // ---- block k+1: pivot sweeps (on the tile just updated), panel product (reads block k's new pivot column)
+        PHX_BEGIN(t_piv2);
+        if (inv_pivot(B.tid, Sig, ld, M, k1, nD, nD2)) return 1;
+        PHX_END(t_piv2, PH_INV_PIVOT);
+        PHX_BEGIN(t_tn2);
+        inv_panel<false>(B, Sig, ld, M, nT, k1, nD, Tn1, Pk, Mp);
+        __syncthreads();
+        PHX_END(t_tn2, PH_INV_TN);
+        // ---- every other tile, one trip: the tiles with neither index in {tk, t1} take both updates, the tiles of
+        // block k's pivot column / pivot block (tile index tk) block k+1's only
+        {
+            const int n2 = nT - 2;
+            const auto skip2 = [tk](int c) { return c < tk ? c : c + 2; };
+            int cnt = 0;
+            for (int b = 0; b < n2; b++) {
+                const int tj = skip2(b);
+                for (int a0 = b; a0 < n2; a0 += INV_RUN) {
+                    if ((cnt++) % B.nwave != B.wave) continue;
+                    double av0[4], av1[4];
+                    inv_av_pk(Pk, Mp, tj, l15, l4, av0);
+                    inv_av_sig(Sig, ld, M, tj, k1, l15, l4, av1);
+                    inv_run<2>(Sig, ld, M, tj, a0, a0 + INV_RUN < n2 ? a0 + INV_RUN : n2, skip2, av0, av1, Tn0, Tn1, l15, l4);
+                }
+            }
+            // tile column tk: rows tk, tk+2, ...
+            const auto rows_k = [tk](int c) { return c == 0 ? tk : tk + 1 + c; };
+            const int nk = nT - tk - 1;                          // tk itself + the tiles below t1
+            for (int a0 = 0; a0 < nk; a0 += INV_RUN) {
+                if ((cnt++) % B.nwave != B.wave) continue;
+                double av1[4];
+                inv_av_sig(Sig, ld, M, tk, k1, l15, l4, av1);
+                inv_run<1>(Sig, ld, M, tk, a0, a0 + INV_RUN < nk ? a0 + INV_RUN : nk, rows_k, zero4, av1, Tn1, Tn1, l15, l4);
+            }
+            // tile row tk: columns b < tk
+            for (int b = 0; b < tk; b++) {
+                if ((cnt++) % B.nwave != B.wave) continue;
+                double av1[4];
+                inv_av_sig(Sig, ld, M, b, k1, l15, l4, av1);
+                inv_run<1>(Sig, ld, M, b, tk, tk + 1, [](int a) { return a; }, zero4, av1, Tn1, Tn1, l15, l4);
+            }
+        }
+        __syncthreads();
+        inv_write_panel(B, Sig, ld, M, Mp, k1, Tn1, nD);
+    }
+    if (tk < nT) {                                               // an odd last block on its own
+        const int k0 = tk * 16;
+        if (inv_pivot(B.tid, Sig, ld, M, k0, nD, nD2)) return 1;
+        inv_panel<false>(B, Sig, ld, M, nT, k0, nD, Tn0, Pk, Mp);
+        __syncthreads();
+        const int n1 = nT - 1;                                   // the last block: the other tiles are 0 .. n1-1
+        int cnt = 0;
+        for (int b = 0; b < n1; b++)
+            for (int a0 = b; a0 < n1; a0 += INV_RUN) {
+                if ((cnt++) % B.nwave != B.wave) continue;
+                double av[4];
+                inv_av_sig(Sig, ld, M, b, k0, l15, l4, av);
+                inv_run<1>(Sig, ld, M, b, a0, a0 + INV_RUN < n1 ? a0 + INV_RUN : n1, [](int a) { return a; }, zero4, av, Tn0, Tn0, l15, l4);
+            }
+        __syncthreads();
+        inv_write_panel(B, Sig, ld, M, Mp, k0, Tn0, nD);
+    }
+    __syncthreads();
+    for (int j = B.wave; j < M; j += B.nwave)
+        for (int i = j + B.lane; i < M; i += 64) {
+            const double v = -Sig[(size_t)j * ld + i];
+            Sig[(size_t)j * ld + i] = v;
+            Sig[(size_t)i * ld + j] = v;
+        }
+    __syncthreads();
+    return 0;
+}
+
+// ---- the whole triangle in registers ---------------------------------------------------------------------------
+// At the sizes most inversions of a grid have (a few hundred columns at most) the blocked sweep above is bound by
+// neither the matrix cores nor bandwidth but by memory round trips: every pivot block costs a chain of them (pivot
+// tile in, panel in, each wave's tiles in and out, panel out) at 1 - 2 us each with 256 workgroups on the chip, ~20 us
+// per block at M = 133 against 1 us of matrix-pipe time (tools/ubench/inverse_rate.py).  Here the matrix makes ONE
+// trip: tile q = a (a + 1) / 2 + b of the lower triangle (row tile a >= column tile b) belongs to wave q mod nwave
+// for the whole inversion and lives in that wave's registers as the accumulator of its matrix ops (S tiles per wave,
+// statically indexed: the slot loops are unrolled, the branches inside are wave-uniform).  Per pivot block the
+// owners put the pivot column (P, in operand order) and the pivot tile into LDS, the pivot tile is swept there, the
+// panel product goes LDS -> matrix cores -> LDS, and every wave updates its own tiles from LDS operands; the tiles of
+// the pivot column / pivot tile take their new values from the panel / the swept tile.  Element by element these
+// are the operations of gm_spd_inverse_blocked in the same order -- the same bits -- with no memory access inside
+// the loop.  Up to S * nwave tiles: S = 24 -> 19 row tiles, M <= 304.
+#define INV_PP 17          // pitch of a pivot-column row group in P: [row tile][pivot s][row in tile]
+template <int S>
+DEVNI int gm_spd_inverse_regs(const Blk &NOALIAS B, const GmWork &NOALIAS W, int M, long long *phx)
+{
+    const int ld = W.ld;
+    const gptr_d Sig = as_global_rw(W.Sig);
+    const int nT = (M + 15) >> 4, Mp = nT * 16, nQ = nT * (nT + 1) / 2;
+    // B is a reference argument of a non-inlined function, i.e. memory: every use inside a loop would be a flat load
+    // (with its wait) -- register copies, taken once
+    const int tid = B.tid, lane = tid & 63;
+    const int wave = uni(B.wave), nw = uni(B.nwave);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    double *const pool = uni_ptr(B.pool);
+    const lptr_d Tn = as_lds(pool), P = Tn + (size_t)Mp * INV_TP, nD = P + (size_t)nT * 16 * INV_PP, nD2 = nD + 16 * 17;
+    // (a << 8 | b) of slot s in a scalar register, -1 = no tile.  Inside the loops the value is passed through an empty
+    // asm so that everything derived from it (LDS addresses, guards) is recomputed where it is used: hoisted out of
+    // the pivot loop those would take ~20 vector registers per slot and push the tiles themselves into scratch.
+    int tab[S];
+    d4 acc[S];
+    PHD_BEGIN(t_ld);
+#define INV_SLOT(s) int ab_ = tab[s]; asm volatile("" : "+s"(ab_)); const int a_ = ab_ >> 8, b_ = ab_ & 255
+#pragma unroll
+    for (int s = 0; s < S; s++) {                               // this wave's tiles
+        const int q = s * nw + wave;
+        int a = (int)((sqrtf(8.0f * (float)q + 1.0f) - 1.0f) * 0.5f);
+        while (a * (a + 1) / 2 > q) a--;
+        while ((a + 1) * (a + 2) / 2 <= q) a++;
+        const bool on = q < nQ;
+        tab[s] = uni(on ? (a << 8) | (q - a * (a + 1) / 2) : -1);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int icol = a * 16 + l15, j = (q - a * (a + 1) / 2) * 16 + l4 + 4 * r;
+            acc[s][r] = (on && icol < M && j < M) ? Sig[(size_t)j * ld + icol] : 0.0;
+        }
+    }
+    PHD_END(t_ld, 16);
+    for (int tk = 0; tk < nT; tk++) {
+        const int k0 = tk * 16;
+        // slots holding a tile of the pivot row / column (scalar, branch-free: the slot loops below then test one bit per
+        // slot instead of walking a chain of compares and branches -- at these sizes branch latency is what a slot costs)
+        unsigned mk = 0, mv = 0;
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            const int ab = tab[s];
+            mv |= (ab >= 0 ? 1u : 0u) << s;
+            mk |= ((ab >= 0 && ((ab >> 8) == tk || (ab & 255) == tk)) ? 1u : 0u) << s;
+        }
+        PHX_BEGIN(t_piv);
+        __syncthreads();                                         // the previous block's readers of P / Tn / nD are done
+        PHD_BEGIN(t_ex);
+        // ---- pivot column and pivot tile -> LDS
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            if (!((mk >> s) & 1u)) continue;
+            INV_SLOT(s);
+            if (a_ == tk && b_ == tk) {                           // lanes of the stored triangle write both mirror images, identity-padded
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int rr = l15, cc = l4 + 4 * r;          // icol = k0 + rr >= j = k0 + cc
+                    if (rr >= cc) {
+                        const bool in = k0 + rr < M;              // then k0 + cc < M too
+                        const double v = in ? acc[s][r] : (rr == cc ? 1.0 : 0.0);
+                        nD[rr * 17 + cc] = v; nD[cc * 17 + rr] = v;
+                    }
+                }
+            } else if (b_ == tk) {                                // tile (a, tk): A(icol, k0 + l4 + 4r)
+#pragma unroll
+                for (int r = 0; r < 4; r++) P[(a_ * 16 + l4 + 4 * r) * INV_PP + l15] = acc[s][r];
+            } else if (a_ == tk) {                                // tile (tk, b): A(j, k0 + l15) by symmetry
+#pragma unroll
+                for (int r = 0; r < 4; r++) P[(b_ * 16 + l15) * INV_PP + l4 + 4 * r] = acc[s][r];
+            }
+        }
+        __syncthreads();
+        PHD_END(t_ex, 17);
+        // ---- the sixteen sweeps inside the pivot tile: one division per element (numerator chosen first); a pivot that is
+        // not positive is noticed by every thread alike and acted upon after the sweeps (what follows it is never used)
+        bool bad = false;
+        {
+            const int r = tid & 15, c = (tid >> 4) & 15;
+#pragma unroll
+            for (int sw = 0; sw < 16; sw++) {
+                const lptr_d src = (sw & 1) ? nD2 : nD, dst = (sw & 1) ? nD : nD2;
+                const double d = src[sw * 17 + sw], prs = src[r * 17 + sw], psc = src[sw * 17 + c], v = src[r * 17 + c];
+                bad |= !(d > 0);
+                const bool rs = r == sw, cs = c == sw;
+                const double num = rs ? (cs ? -1.0 : psc) : (cs ? prs : prs * psc);
+                const double t = num / d;
+                if (tid < 256) dst[r * 17 + c] = (rs || cs) ? t : v - t;
+                __syncthreads();
+            }
+        }
+        if (bad) return 1;
+        PHX_END(t_piv, PH_INV_PIVOT);
+        PHX_BEGIN(t_tn);
+        // ---- panel product Tn = (pivot column) x (swept tile), rows outside the block
+        for (int ti = wave; ti < nT; ti += nw) {
+            const int i = ti * 16 + l15;
+            const bool live = i < M && ti != tk;
+            d4 t4 = d4{0, 0, 0, 0};
+            double av[4], bw[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                const int kc = k0 + kk * 4 + l4;
+                const double v = P[(size_t)(ti * 16 + kk * 4 + l4) * INV_PP + l15];
+                av[kk] = (live && kc < M) ? v : 0.0;
+                bw[kk] = nD[(kk * 4 + l4) * 17 + l15];
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) t4 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bw[kk], t4, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; r++) Tn[(size_t)(ti * 16 + l4 + 4 * r) * INV_TP + l15] = t4[r];
+        }
+        __syncthreads();
+        PHX_END(t_tn, PH_INV_TN);
+        PHD_BEGIN(t_tr);
+        // ---- every wave's own tiles (the branches are wave-uniform)
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            if (!((mv >> s) & 1u)) continue;
+            INV_SLOT(s);
+            if (!((mk >> s) & 1u)) {                              // A += Tn[a] * (pivot column rows of b)'
+                double av[4], bv[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) {
+                    const int kc = k0 + kk * 4 + l4, jrow = b_ * 16 + l15;
+                    const double v = P[(b_ * 16 + kk * 4 + l4) * INV_PP + l15];
+                    av[kk] = (jrow < M && kc < M) ? v : 0.0;
+                    bv[kk] = Tn[(a_ * 16 + l15) * INV_TP + kk * 4 + l4];
+                }
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], acc[s], 0, 0, 0);
+            } else if (a_ == tk && b_ == tk) {                    // pivot tile <- swept tile
+#pragma unroll
+                for (int r = 0; r < 4; r++) if (k0 + l15 < M && k0 + l4 + 4 * r < M) acc[s][r] = nD[l15 * 17 + l4 + 4 * r];
+            } else if (b_ == tk) {                                // pivot column below the block <- -Tn
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int i = a_ * 16 + l15, kc = k0 + l4 + 4 * r;
+                    if (i < M && kc < M) acc[s][r] = -Tn[i * INV_TP + l4 + 4 * r];
+                }
+            } else {                                              // ... and left of it (row tile tk, column tile b)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int i = b_ * 16 + l4 + 4 * r, kc = k0 + l15;
+                    if (i < M && kc < M) acc[s][r] = -Tn[i * INV_TP + l15];
+                }
+            }
+        }
+        PHD_END(t_tr, 20);
+    }
+    PHD_BEGIN(t_st);
+    // ---- out: negated, both mirror images (the diagonal tiles only from their stored triangle)
+#pragma unroll
+    for (int s = 0; s < S; s++) {
+        INV_SLOT(s);
+        if (ab_ < 0) continue;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int icol = a_ * 16 + l15, j = b_ * 16 + l4 + 4 * r;
+            if (icol < M && j < M && icol >= j) {
+                const double v = -acc[s][r];
+                Sig[(size_t)j * ld + icol] = v;
+                Sig[(size_t)icol * ld + j] = v;
+            }
+        }
+    }
+    __syncthreads();
+    PHD_END(t_st, 21);
+    return 0;
+#undef INV_SLOT
+}
+// LDS of the register form: Tn (Mp x 18) + P (Mp x 17) + two pivot tiles
+DEV bool inv_regs_fits(const Blk &NOALIAS B, int M, int slots)
+{
+    const int nT = (M + 15) >> 4, Mp = nT * 16;
+    return nT * (nT + 1) / 2 <= slots * B.nwave && Mp * (INV_TP + INV_PP) + 2 * 16 * 17 <= B.pool_n;
+}
+
+DEV int gm_spd_inverse(const Blk &NOALIAS B, const GmWork &NOALIAS W, int M, long long *phx = nullptr, int pair = 3)
 {
     (void)phx;
     const int Mp = ((M + 15) >> 4) * 16;
+    if (pair & 2) {                                              // bit 1: the register form while the triangle fits
+        if (M > 16 && inv_regs_fits(B, M, 4)) return gm_spd_inverse_regs<4>(B, W, M, phx);
+        if (M > 16 && inv_regs_fits(B, M, 8)) return gm_spd_inverse_regs<8>(B, W, M, phx);
+        if (M > 16 && inv_regs_fits(B, M, 12)) return gm_spd_inverse_regs<12>(B, W, M, phx);
+        if (M > 16 && inv_regs_fits(B, M, 16)) return gm_spd_inverse_regs<16>(B, W, M, phx);
+        if (M > 16 && inv_regs_fits(B, M, 20)) return gm_spd_inverse_regs<20>(B, W, M, phx);
+        if (M > 16 && inv_regs_fits(B, M, 22)) return gm_spd_inverse_regs<22>(B, W, M, phx);
+    }
+    if ((pair & 1) && M > 32 && W.Tn && 2 * Mp * INV_TP + 2 * 16 * 17 <= B.pool_n) return gm_spd_inverse_paired(B, W, M, phx);
     if (M > 16 && Mp * INV_TP + 2 * 16 * 17 <= B.pool_n) {
         const lptr_d Tn = as_lds(B.pool);
         return gm_spd_inverse_blocked(B, W, M, phx, Tn, Tn + (size_t)Mp * INV_TP);
@@ -1257,7 +1732,7 @@ DEV int gm_spd_inverse(const Blk &B, const GmWork &W, int M, long long *phx = nu
 }
 
 // H = beta G[used, used] + diag(A) into W.H and W.Sig (MainEff.c:1841-1876)
-DEV void gm_hessian_build(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScalars &S)
+DEV void gm_hessian_build(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const GmWork &NOALIAS W, int K, GmScalars &NOALIAS S)
 {
     const int M = S.M, ld = W.ld;
     const double beta = S.beta;
@@ -1309,12 +1784,12 @@ DEV void gm_hessian_build(const Blk &B, const FoldDev &F, const GmWork &W, int K
 }
 
 // blocked inverse: per 16-pivot step one panel product per row tile + the triangle of trailing tiles
-DEV void gm_inverse_count(const Blk &B, GmScalars &S, int M)
+DEV void gm_inverse_count(const Blk &NOALIAS B, GmScalars &NOALIAS S, int M)
 {
     if (M > 16) CNT(const int64_t nT = (M + 15) >> 4; c.mfma_tiles += nT * (nT + (nT - 1) * nT / 2));
 }
 // mu = beta Sigma v1 (v1 = Phi't), one fma chain per row over the columns in order
-DEV void gm_mu_update(const Blk &B, const GmWork &W, int M, double beta)
+DEV void gm_mu_update(const Blk &NOALIAS B, const GmWork &NOALIAS W, int M, double beta)
 {
     const int ld = W.ld;
     {   // the vector from LDS, Sigma through a global pointer: the row loads of a thread pipeline
@@ -1335,7 +1810,7 @@ DEV void gm_mu_update(const Blk &B, const GmWork &W, int M, double beta)
 // On the device the (column id, coefficient, 1/|x|) triples are staged in LDS first (gm_stage_model), so
 // the only memory access per term is the coalesced design-column load and nothing sits behind a dependent
 // used[] -> rscale[] address chain; the arithmetic is the same expression in the same order either way.
-DEV void gm_stage_model(const Blk &B, const FoldDev &F, const GmWork &W, int M, const double *vec)
+DEV void gm_stage_model(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const GmWork &NOALIAS W, int M, const double *vec)
 {
     double *lc = B.pool, *lr = B.pool + M;
     int *lu = (int *)(B.pool + 2 * M);
@@ -1343,7 +1818,7 @@ DEV void gm_stage_model(const Blk &B, const FoldDev &F, const GmWork &W, int M, 
     PAR(j, M) { const int uj = W.used[j]; lu[j] = uj; lc[j] = vec[j]; lr[j] = F.rscale[uj]; }
     blk_sync(B);
 }
-DEV double gm_model_at(const Blk &B, const FoldDev &F, const GmWork &, int M, const double *, int N, int h)
+DEV double gm_model_at(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const GmWork &, int M, const double *, int N, int h)
 {
     const lptr_d lc = as_lds(B.pool), lr = as_lds(B.pool + M);
     const lptr_i lu = as_lds((int *)(B.pool + 2 * M));
@@ -1354,7 +1829,7 @@ DEV double gm_model_at(const Blk &B, const FoldDev &F, const GmWork &, int M, co
     return v;
 }
 // two samples at once (twice the design-column loads in flight; each sum is the same chain as above)
-DEV void gm_model_at2(const Blk &B, const FoldDev &F, const GmWork &, int M, const double *, int N, int h0, int h1, double &v0, double &v1)
+DEV void gm_model_at2(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const GmWork &, int M, const double *, int N, int h0, int h1, double &v0, double &v1)
 {
     const lptr_d lc = as_lds(B.pool), lr = as_lds(B.pool + M);
     const lptr_i lu = as_lds((int *)(B.pool + 2 * M));
@@ -1371,7 +1846,7 @@ DEV void gm_model_at2(const Blk &B, const FoldDev &F, const GmWork &, int M, con
 }
 
 // XOR over the workgroup (decision trace: order-free hash of bit patterns)
-DEV unsigned long long blk_xor64(const Blk &B, unsigned long long v)
+DEV unsigned long long blk_xor64(const Blk &NOALIAS B, unsigned long long v)
 {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v ^= __shfl_xor(v, o, 64);

@@ -53,12 +53,13 @@ struct GmScalars {
     // dead work): gm_inner.  kind: 0 none, 1 re-estimate, 2 single add, 3 delete, 4 run of adds.
     struct Pending { int kind = 0, M = 0, T = 0, jj = -1, row = -1; double beta = 0, c1 = 0, c2 = 0; } pend;
     int defer = 1;
+    int inv_pair = 3;                      // blocked inverse (gm_dev.h): bit 0 two pivot blocks per trip through memory, bit 1 the register form; PAREBEN_INV_PAIR=<bits>
     double *outer_log = nullptr;           // per-fit entries with verbose > 2: (err, intercept | -, residual variance | -) per outer iteration
 };
 #define CNT(stmt) do { if (B.tid == 0) { FitCounters &c = *S.c; stmt; } } while (0)
 
 // S_out/Q_out from S_in/Q_in, MainEff.c:1320-1338 and :664-671
-DEVNI void gm_refresh_out(const Blk &B, const GmWork &W, int K)
+DEVNI void gm_refresh_out(const Blk &NOALIAS B, const GmWork &NOALIAS W, int K)
 {
     PAR(i, K) {
         double s = W.Sin[i], q = W.Qin[i];
@@ -77,7 +78,7 @@ DEVNI void gm_refresh_out(const Blk &B, const GmWork &W, int K)
 
 // S_in / Q_in update of feature i from a = sum_j G[used[j], i] * vec[j].
 // mode 0: re-estimate (:577-587), 1: add (:1699-1711), 2: delete (:1800-1808).
-DEV void gm_sq_apply(const GmWork &W, int mode, double beta, double c1, double c2, const double *newrow, int i, double a)
+DEV void gm_sq_apply(const GmWork &NOALIAS W, int mode, double beta, double c1, double c2, const double *newrow, int i, double a)
 {
     if (mode == 0) {                             // c1 = kappa, c2 = mu_jj
         const double ba = beta * a;
@@ -97,7 +98,7 @@ DEV void gm_sq_apply(const GmWork &W, int mode, double beta, double c1, double c
 // Sigma <- H^-1 for the SPD M x M matrix held in Sig (in place, Gauss-Jordan without pivoting:
 // the pivots are the Cholesky pivots squared, so a non-positive pivot means "not SPD").
 // Stands in for dpotrf+dpotri (:1346-1369).  Returns 0 on success.
-DEVNI int gm_spd_inverse_scalar(const Blk &B, const GmWork &W, int M)
+DEVNI int gm_spd_inverse_scalar(const Blk &NOALIAS B, const GmWork &NOALIAS W, int M)
 {
     const int ld = W.ld;
     for (int k = 0; k < M; k++) {
@@ -130,7 +131,7 @@ DEVNI int gm_spd_inverse_scalar(const Blk &B, const GmWork &W, int M)
 #include GM_PHASES_H
 
 // Full statistics, MainEff.c:1209-1341 (Q3: gamma[0] is left alone).
-DEV void gm_fullstat(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScalars &S,
+DEV void gm_fullstat(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const GmWork &NOALIAS W, int K, GmScalars &NOALIAS S,
                      bool very_first)
 {
     const int M = S.M, ld = W.ld;
@@ -165,7 +166,7 @@ DEV void gm_fullstat(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmS
 
 // Per-feature marginal-likelihood change and action, MainEff.c:1372-1582.  Returns the arg-max
 // feature and its value; ties are resolved in the reference's visiting order (below).
-DEVNI int gm_delta_ml(const Blk &B, const GmWork &W, int K, int N, int M, double lambda, double alpha,
+DEVNI int gm_delta_ml(const Blk &NOALIAS B, const GmWork &NOALIAS W, int K, int N, int M, double lambda, double alpha,
                     double residual, double varY, int iter, int i_iter, int epis, int *any_del_out, double *best)
 {
     const double l1 = lambda * alpha, l2 = lambda * (1 - alpha);
@@ -259,7 +260,7 @@ DEVNI int gm_delta_ml(const Blk &B, const GmWork &W, int K, int N, int M, double
 }
 
 // ordered list of features with dML >= cutoff (ascending index), MainEff.c:463-473
-DEVNI int gm_collect(const Blk &B, const GmWork &W, int K, double cutoff)
+DEVNI int gm_collect(const Blk &NOALIAS B, const GmWork &NOALIAS W, int K, double cutoff)
 {
     // every thread takes a contiguous slice of the features: one count, ONE block scan, one ordered write
     const int per = (K + B.nthr - 1) / B.nthr, i0 = B.tid * per, i1 = i0 + per < K ? i0 + per : K;
@@ -277,7 +278,7 @@ DEVNI int gm_collect(const Blk &B, const GmWork &W, int K, double cutoff)
 // `defer` (all four actions): leave the K-space half -- the Gram-row sweep with the S_in / Q_in update -- in S.pend
 // instead of running it (gm_flush_pending runs it later, or nobody does: gm_inner).  The vector stays in W.v2 (W.vb for
 // a run of adds), which nothing between here and the flush writes.
-DEVNI void gm_reestimate(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScalars &S, int jj, double newA, bool defer)
+DEVNI void gm_reestimate(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const GmWork &NOALIAS W, int K, GmScalars &NOALIAS S, int jj, double newA, bool defer)
 {
     const int M = S.M, ld = W.ld;
     PAR(i, M) W.v2[i] = W.Sig[(size_t)jj * ld + i];
@@ -297,7 +298,7 @@ DEVNI void gm_reestimate(const Blk &B, const FoldDev &F, const GmWork &W, int K,
 }
 
 // add feature nu, MainEff.c:1585-1723 + :613-627
-DEVNI void gm_add(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScalars &S, int nu, int rid, double newA, bool defer)
+DEVNI void gm_add(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const GmWork &NOALIAS W, int K, GmScalars &NOALIAS S, int nu, int rid, double newA, bool defer)
 {
     const int M = S.M, ld = W.ld;
     const double beta = S.beta;
@@ -335,7 +336,7 @@ DEVNI void gm_add(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScal
 }
 
 // the K-space half a block's last unit left in S.pend (gm_inner)
-DEV void gm_flush_pending(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScalars &S)
+DEV void gm_flush_pending(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const GmWork &NOALIAS W, int K, GmScalars &NOALIAS S)
 {
     const GmScalars::Pending p = S.pend;
     S.pend.kind = 0;
@@ -347,7 +348,7 @@ DEV void gm_flush_pending(const Blk &B, const FoldDev &F, const GmWork &W, int K
 
 // delete slot jj, MainEff.c:1725-1822 + :640-651.  `nu` is the feature the action named; it
 // differs from used[jj] only on the reference's stale-slot path.
-DEVNI void gm_delete(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScalars &S, int jj, int nu, bool defer)
+DEVNI void gm_delete(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const GmWork &NOALIAS W, int K, GmScalars &NOALIAS S, int jj, int nu, bool defer)
 {
     const int M = S.M, ld = W.ld, last = M - 1;
     PAR(i, M) W.v2[i] = W.Sig[(size_t)jj * ld + i];
@@ -391,14 +392,14 @@ DEVNI void gm_delete(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmS
 }
 
 // H = beta Phi'Phi + diag(A); Sigma = H^-1; mu = beta Sigma Phi't.  MainEff.c:1841-1921
-DEVNI int gm_final_update(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScalars &S)
+DEVNI int gm_final_update(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const GmWork &NOALIAS W, int K, GmScalars &NOALIAS S)
 {
     const int M = S.M, ld = W.ld;
     const double beta = S.beta;
     gm_hessian_build(B, F, W, K, S);
     PAR(l, M) W.v1[l] = W.bt[W.used[l]];
     blk_sync(B);
-    { PH_BEGIN(); const int bad = gm_spd_inverse(B, W, M, S.ph); PH_END(PH_INVERSE); if (bad) return 1; }
+    { PH_BEGIN(); const int bad = gm_spd_inverse(B, W, M, S.ph, S.inv_pair); PH_END(PH_INVERSE); if (bad) return 1; }
     gm_inverse_count(B, S, M);
     PH_BEGIN();
     gm_mu_update(B, W, M, beta);
@@ -409,7 +410,7 @@ DEVNI int gm_final_update(const Blk &B, const FoldDev &F, const GmWork &W, int K
 
 // ---- decision trace (diagnostics only: S.trace is null in every production launch) -------------------------
 DEV unsigned long long gm_dbits(double v) { unsigned long long u; __builtin_memcpy(&u, &v, 8); return u; }
-DEV double blk_max(const Blk &B, double v)
+DEV double blk_max(const Blk &NOALIAS B, double v)
 {
     double bv; int bi;
     blk_argmax(B, v, 0, &bv, &bi);
@@ -417,13 +418,13 @@ DEV double blk_max(const Blk &B, double v)
     return bv;
 }
 // the record of this inner iteration, or null (thread-uniform)
-DEV unsigned long long *gm_trace_rec(const GmScalars &S)
+DEV unsigned long long *gm_trace_rec(const GmScalars &NOALIAS S)
 {
     return (S.trace && (long long)S.trace[0] < S.trace_cap) ? S.trace + TR_NSLOT * (S.trace[0] + 1) : nullptr;
 }
 // the decision: arg-max feature, its action and value, the runner-up, the block cut-off and the relative distance of
 // the nearest dML to it (what a last-bit change would have to bridge to alter the to-do list)
-DEVNI void gm_trace_decision(const Blk &B, const GmWork &W, int K, const GmScalars &S, unsigned long long *tr, int iter, int i_iter,
+DEVNI void gm_trace_decision(const Blk &NOALIAS B, const GmWork &NOALIAS W, int K, const GmScalars &NOALIAS S, unsigned long long *tr, int iter, int i_iter,
                              int nu, double best, int worthwhile, int n_todo)
 {
     double cutoff = 0;
@@ -449,7 +450,7 @@ DEVNI void gm_trace_decision(const Blk &B, const GmWork &W, int K, const GmScala
 }
 // the state after the iteration: XOR of the bit patterns of S_in, Q_in and (Sigma, mu) -- order-free, so equal
 // hashes on two builds mean equal bits whatever the layout
-DEVNI void gm_trace_state(const Blk &B, const GmWork &W, int K, const GmScalars &S, unsigned long long *tr, int sel)
+DEVNI void gm_trace_state(const Blk &NOALIAS B, const GmWork &NOALIAS W, int K, const GmScalars &NOALIAS S, unsigned long long *tr, int sel)
 {
     unsigned long long hs = 0, hq = 0, hg = 0;
     PAR(i, K) { hs ^= gm_dbits(W.Sin[i]); hq ^= gm_dbits(W.Qin[i]); }
@@ -470,8 +471,8 @@ DEVNI void gm_trace_state(const Blk &B, const GmWork &W, int K, const GmScalars 
 // One call of the inner routine (MainEff.c:248-809) for outer iteration `iter`.  On return
 // *cs = sum_i Csum_i and *csy = Csum.y with Csum the column sums of
 // C^-1 = beta I - beta^2 Phi Sigma Phi' (:741-781, :172-187), formed in O(N M + M^2).
-DEV int gm_inner(const Blk &B, const FoldDev &F, const GmWork &W, int K, double lambda, double alpha,
-                 GmScalars &S, int iter, double residual, double varY, double *cs, double *csy)
+DEV int gm_inner(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const GmWork &NOALIAS W, int K, double lambda, double alpha,
+                 GmScalars &NOALIAS S, int iter, double residual, double varY, double *cs, double *csy)
 {
     const int N = F.N, ld = W.ld;
     const bool first = iter <= 1;
@@ -682,8 +683,8 @@ DEV int gm_inner(const Blk &B, const FoldDev &F, const GmWork &W, int K, double 
 
 // The whole fit: MainEff.c:55-242.  On return S.b = intercept, S.beta = noise precision,
 // W.used/W.mu/W.Sig hold the model (mu in normalised-column units).
-DEV void gm_fit(const Blk &B, const FoldDev &F, const GmWork &W, int K, double lambda, double alpha,
-                GmScalars &S)
+DEV void gm_fit(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const GmWork &NOALIAS W, int K, double lambda, double alpha,
+                GmScalars &NOALIAS S)
 {
     S.b = F.ymean;
     S.status = 0;
@@ -711,7 +712,7 @@ DEV void gm_fit(const Blk &B, const FoldDev &F, const GmWork &W, int K, double l
 }
 
 // fold score, R/GetModelError.R:7-32: SSE of the held-out rows under the fitted model
-DEV double gm_fold_sse(const Blk &B, const FoldDev &F, const GmWork &W, const GmScalars &S)
+DEV double gm_fold_sse(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const GmWork &NOALIAS W, const GmScalars &NOALIAS S)
 {
     const int nte = F.nte, M = S.M;
     double part = 0;

@@ -26,6 +26,8 @@
 #define GS_FP _Pragma("clang fp contract(off)")
 #endif
 
+#include "gs_log.h"   // the logarithm, correctly rounded (double-double): one last bit of a dML decides actions on tied twins
+
 // a wave-uniform pointer in scalar registers on the device (loads through it become scalar loads); the pointer itself on the host
 #ifdef PAREBEN_HOST_EMUL
 #define GS_UNI(p) (p)
@@ -386,20 +388,20 @@ DEV int gs_delta_ml(const Blk &B, const GmWork &W, int K, int N, int M, double l
         const double disc = bq * bq - 4 * a * g;
         if (a < 0 && disc > 0) {
             const double r = (-bq - sqrt(disc)) / (2 * a);
-            const double L = (log(r / (r + so + l2)) + qo * qo / (r + so + l2)) * 0.5 - l1 / r;
+            const double L = (gs_log(r / (r + so + l2)) + qo * qo / (r + so + l2)) * 0.5 - l1 / r;
             if (L > 0) {
                 W.aroot[i] = r + l2;
                 if (l >= 0) {
                     act = ACT_REEST;
                     const double o = W.A[l] - l2;
-                    d_ml = 0.5 * (log(r * (o + so + l2) / (o * (r + so + l2))) + qo * qo * (1 / (r + so + l2) - 1 / (o + so + l2))) - l1 * (1 / r - 1 / o);
+                    d_ml = 0.5 * (gs_log(r * (o + so + l2) / (o * (r + so + l2))) + qo * qo * (1 / (r + so + l2) - 1 / (o + so + l2))) - l1 * (1 / r - 1 / o);
                 } else { act = ACT_ADD; d_ml = L; my_add = 1; }
             }
         } else if (l >= 0 && M > 1) {
             my_del = 1;
             act = ACT_DEL;
             const double o = W.A[l] - l2;
-            const double L = (log(o / (o + so + l2)) + qo * qo / (o + so + l2)) * 0.5 - l1 / o;
+            const double L = (gs_log(o / (o + so + l2)) + qo * qo / (o + so + l2)) * 0.5 - l1 / o;
             d_ml = -L;
         }
         W.act[i] = (signed char)act;
@@ -657,7 +659,7 @@ DEV int gs_inner(const Blk &B, const FoldDev &F, const GmWork &W, const GsExtra 
                     if (l >= 0) jj = l;
                     else { S.status |= ST_STALE; if (jj < 0 || jj >= S.M) { S.status |= ST_ABORT; return 1; } }
                 }
-                if (sel == ACT_REEST && fabs(log(newA) - log(W.A[jj])) <= S.v.reest_tol && any_del == 0) sel = ACT_TERM;
+                if (sel == ACT_REEST && fabs(gs_log(newA) - gs_log(W.A[jj])) <= S.v.reest_tol && any_del == 0) sel = ACT_TERM;
                 blk_sync(B);
                 const int M = S.M;
                 bool upd = false;
@@ -814,7 +816,7 @@ DEV int gs_inner(const Blk &B, const FoldDev &F, const GmWork &W, const GsExtra 
             if (nb > 1e6 / vt) nb = 1e6 / vt;
             const double beta_old = S.beta;
             S.beta = nb;
-            const double dlb = log(nb) - log(beta_old);
+            const double dlb = gs_log(nb) - gs_log(beta_old);
             GS_T1(4);
             if (fabs(dlb) > 1e-6) {
                 gs_final_update(B, F, W, X, S);

@@ -385,6 +385,7 @@ struct CvParams {
     int early;                         // share from the start (few fits per workgroup)
     int heavy_m;                       // active-set size from which a fit shares its phases from the start
     int defer;                         // hold back the sweep of a block's last unit (gm_inner); PAREBEN_DEFER=0: off
+    int inv_pair;                      // forms of the blocked inverse (gm_dev.h): bit 0 two pivot blocks per trip, bit 1 register-resident; PAREBEN_INV_PAIR=<bits>, default 3
     int queue_sys;                     // the queue head is shared by several GPUs (pinned host memory, pareben_cv_grid_multi)
     size_t offX; int nmax;             // strict-order mode (gm_cv_strict_kernel): the extra arrays of gm_strict.h
     GmVariant v;
@@ -532,7 +533,7 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_EU) void gm_cv_kernel(Cv
         S.v = P.v;
         S.share = &sh;
         S.fold = f;
-        S.defer = P.defer;
+        S.defer = P.defer; S.inv_pair = P.inv_pair;
 #ifdef PAREBEN_PHASE_TIMERS
         if (threadIdx.x < PH_N) s_ph[threadIdx.x] = 0;
         __syncthreads();
@@ -635,7 +636,7 @@ struct FitParams {
     FsJob *jobs; int *active; int *queue; const FoldDev *folds; size_t ws_stride;
     unsigned long long *trace; long long trace_cap;    // decision trace (pareben_set_trace); null = off
     double *outer_log;                                 // verbose > 2: 3 doubles per outer iteration; null = off
-    int defer;
+    int defer, inv_pair;
     size_t offX; int nmax;                             // strict-order mode (gm_fit_strict_kernel)
 };
 
@@ -672,7 +673,7 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_EU) void gm_fit_kernel(F
     S.ph = s_ph;
     S.v = P.v;
     if (P.jobs) { S.share = &sh; S.fold = 0; }
-    S.trace = P.trace; S.trace_cap = P.trace_cap; S.outer_log = P.outer_log; S.defer = P.defer;
+    S.trace = P.trace; S.trace_cap = P.trace_cap; S.outer_log = P.outer_log; S.defer = P.defer; S.inv_pair = P.inv_pair;
     gm_fit(B, P.F, W, K, P.lambda, P.alpha, S);
     if (threadIdx.x == 0 && P.active) AT_ADD(P.active, -1);        // the helpers may go (every path of the owner gets here)
     const int M = S.M, ld = W.ld;
@@ -1283,6 +1284,7 @@ static int run_enqueue(pareben_ctx *c, int n_cells, const double *alpha, const d
     P.early = (D.d_jobs && (share_mode == 2 || (share_mode < 0 && n_units / n_sharers <= 10 * blocks))) ? 1 : 0;
     { const char *hm = getenv("PAREBEN_HEAVY_M"); P.heavy_m = share_mode == 1 ? (1 << 30) : (hm ? atoi(hm) : 384); }
     { const char *df = getenv("PAREBEN_DEFER"); P.defer = (df && atoi(df) == 0) ? 0 : 1; }
+    { const char *ip = getenv("PAREBEN_INV_PAIR"); P.inv_pair = ip ? atoi(ip) & 3 : 3; }
     if (binom) {
         BmCvParams Q;
         Q.folds = c->d_folds; Q.alpha = D.d_alpha; Q.lambda = D.d_lambda; Q.order = D.d_order; Q.queue = queue; Q.queue_sys = shared_queue ? 1 : 0;
@@ -1739,6 +1741,7 @@ static int fit_one(int prior, int epis, const double *basis, const double *targe
         P.p = k; P.v = c->variant;
         P.trace = nullptr; P.trace_cap = 0; P.outer_log = nullptr;
         { const char *df = getenv("PAREBEN_DEFER"); P.defer = (df && atoi(df) == 0) ? 0 : 1; }
+    { const char *ip = getenv("PAREBEN_INV_PAIR"); P.inv_pair = ip ? atoi(ip) & 3 : 3; }
         if (trace_host) {
             CK(dmalloc(&d_trace, (size_t)TR_NSLOT * (trace_cap + 1)));
             CK(hipMemset(d_trace, 0, sizeof(unsigned long long) * TR_NSLOT * (trace_cap + 1)));
@@ -1948,6 +1951,66 @@ extern "C" int pareben_diag_fullstat(int M, int K, int blocks, int reps, double 
     float ms = 0; hipEventElapsedTime(&ms, e0, e1);
     *ms_out = ms / reps;
     hipFree(ws); hipFree(G); hipEventDestroy(e0); hipEventDestroy(e1);
+    return PAREBEN_OK;
+}
+// Diagnostic build only (tools/ubench/inverse_rate.py): the blocked inverse alone on `blocks` workgroups, each on its own
+// SPD matrix (diagonally dominant, cap = `cap` so that the matrices lie as far apart as in a real launch); per repetition
+// the upper-stored triangle is copied from W.H into W.Sig and inverted.  phase_out[PH_N]: block 0's phase ticks
+// (-DPAREBEN_PHASE_TIMERS), else zeros.
+struct DiagInvParams { char *ws; size_t stride, offK, offSig, offM; int K, cap, M, reps, pair; long long *ph; double *chk; };
+__global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_EU) void diag_inverse_kernel(DiagInvParams P)
+{
+    const Blk B = make_blk();
+    __shared__ long long s_ph[PH_N];
+    GmWork W = ws_carve(P.ws + (size_t)blockIdx.x * P.stride, P.K, P.cap, P.offK, P.offSig, P.offM);
+    const int M = P.M, ld = W.ld;
+    if (threadIdx.x < PH_N) s_ph[threadIdx.x] = 0;
+    for (int e = threadIdx.x; e < M * M; e += blockDim.x) {
+        const int j = e / M, i = e - j * M;
+        if (i >= j) {
+            const unsigned h = (unsigned)(i * 7919 + j * 104729 + blockIdx.x * 31) * 2654435761u;
+            W.H[(size_t)j * ld + i] = (i == j) ? 2.0 + 0.01 * (h % 97) : ((double)((h >> 8) % 2001) - 1000.0) * (1e-3 / M);
+        }
+    }
+    __syncthreads();
+    int bad = 0;
+    for (int r = 0; r < P.reps; r++) {
+        for (int e = threadIdx.x; e < M * M; e += blockDim.x) {
+            const int j = e / M, i = e - j * M;
+            if (i >= j) W.Sig[(size_t)j * ld + i] = W.H[(size_t)j * ld + i];
+        }
+        __syncthreads();
+        bad |= gm_spd_inverse(B, W, M, s_ph, P.pair);
+    }
+    if (threadIdx.x == 0) {
+        if (blockIdx.x == 0 && P.ph) for (int k = 0; k < PH_N; k++) P.ph[k] = s_ph[k];
+        double c = bad ? -1.0 : 0.0;
+        if (!bad) for (int i = 0; i < M; i++) c += W.Sig[(size_t)i * ld + i] + W.Sig[(size_t)(M - 1) * ld + i];
+        P.chk[blockIdx.x] = c;
+    }
+}
+extern "C" int pareben_diag_inverse(int M, int cap, int blocks, int reps, int pair, double *ms_out, long long *phase_out, double *chk_out)
+{
+    const int K = 64;
+    WsLayout L = ws_layout(K, cap);
+    char *ws = nullptr; long long *ph = nullptr; double *chk = nullptr;
+    if (hipMalloc((void **)&ws, L.bytes * (size_t)blocks) != hipSuccess) return PAREBEN_ENOMEM;
+    hipMalloc((void **)&ph, sizeof(long long) * PH_N); hipMalloc((void **)&chk, sizeof(double) * blocks);
+    hipMemset(ws, 0, L.bytes * (size_t)blocks); hipMemset(ph, 0, sizeof(long long) * PH_N);
+    DiagInvParams P{ws, L.bytes, L.offK, L.offSig, L.offM, K, cap, M, 1, pair, ph, chk};
+    hipFuncSetAttribute((const void *)diag_inverse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FIT_BYTES);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(diag_inverse_kernel, dim3(blocks), dim3(FIT_THREADS), LDS_FIT_BYTES, 0, P);   // warm-up
+    P.reps = reps;
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(diag_inverse_kernel, dim3(blocks), dim3(FIT_THREADS), LDS_FIT_BYTES, 0, P);
+    hipEventRecord(e1, 0);
+    if (hipDeviceSynchronize() != hipSuccess) return PAREBEN_EHIP;
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    *ms_out = ms / reps;
+    hipMemcpy(phase_out, ph, sizeof(long long) * PH_N, hipMemcpyDeviceToHost);
+    hipMemcpy(chk_out, chk, sizeof(double) * blocks, hipMemcpyDeviceToHost);
+    hipFree(ws); hipFree(ph); hipFree(chk); hipEventDestroy(e0); hipEventDestroy(e1);
     return PAREBEN_OK;
 }
 #endif

@@ -148,7 +148,7 @@ DEV void gm_gc_add(const Blk &, const FoldDev &, const GmWork &, int, const GmSc
 // runs of adds are a device optimisation: every add takes the single-action path here
 DEV int gm_add_run(const Blk &, const FoldDev &, const GmWork &, int, GmScalars &, int, int, bool) { return 0; }
 DEV void gm_flush_add_run(const Blk &, const FoldDev &, const GmWork &, int, GmScalars &, int, int, double) {}
-DEV int gm_spd_inverse(const Blk &B, const GmWork &W, int M, long long *phx = nullptr) { (void)phx; return gm_spd_inverse_scalar(B, W, M); }
+DEV int gm_spd_inverse(const Blk &B, const GmWork &W, int M, long long *phx = nullptr, int pair = 1) { (void)phx; (void)pair; return gm_spd_inverse_scalar(B, W, M); }
 
 // H = beta G[used, used] + diag(A) into W.H and W.Sig (MainEff.c:1841-1876)
 DEV void gm_hessian_build(const Blk &B, const FoldDev &F, const GmWork &W, int K, GmScalars &S)

@@ -59,7 +59,7 @@ def test_strict_mode_brings_the_subset_table_onto_real_r(fulltest, monkeypatch):
         E, st, cnt = ctx.run(alpha[cells], lam[cells])
     assert np.all(st & 9 == 0)
     rel = np.abs(E - want[cells]) / want[cells]
-    assert rel.max() < 1e-9, rel
+    assert rel.max() < 1e-9, [(cells[c], f + 1, float(rel[c, f])) for c, f in np.argwhere(rel >= 1e-9)]
     k = cells.index(opt)
     assert abs(E[k].mean() - float(d["summary_MSE"][idx])) <= 1e-6 * float(d["summary_MSE"][idx])
     listed = [(cells.index(p["cell"]), p["fold"] - 1) for p in fx["pairs"]]
