@@ -314,7 +314,7 @@ def main():
                   "nominal_fp64_flops_per_launch": flops_nom,
                   "note": "flops executed on the FP64 matrix cores (mfma_tiles counter x 8192: symmetric full-stat schedule + blocked "
                           "inverse, padding to 16-row blocks included) over the FP64 matrix peak = matrix-pipe busy fraction"}
-            gram_flops = float(sum(float((folds != f + 1).sum()) * K * (K + 1) for f in range(nF)))   # executed: lower triangle
+            gram_flops = float(sum(2.0 * float((folds != f + 1).sum()) * K * K for f in range(nF)))   # executed: gram_kernel computes all K^2 entries (the symmetric variant was dropped, tools/gram_rate.py)
             if fit_ms >= prep_ms:
                 bound = "mfma" if mf["frac"] >= 0.05 else "hbm"
                 main_obj = mf if bound == "mfma" else hbm

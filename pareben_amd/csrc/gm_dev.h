@@ -1102,162 +1102,8 @@ DEV void gm_flush_add_run(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const 
 #define INV_TT 2           // tiles of the trailing update each wave keeps in flight
 #endif
 #ifndef INV_RUN
-#define INV_RUN 4          // tiles per run (multiple of INV_TT)
+#define INV_RUN 8          // tiles per run (multiple of INV_TT)
 #endif
-// TP: where the M x 16 panel Tn lives -- LDS while it fits (M <= 1040 with the 152 KB pool), else the fit's own
-// scratch in HBM (W.Tn, L2-resident: 2048 x 18 doubles = 295 KB); the two 16 x 17 pivot blocks are always in LDS.
-template <class TP>
-DEVNI int gm_spd_inverse_blocked(const Blk &NOALIAS B_, const GmWork &NOALIAS W, int M, long long *phx, const TP Tn, const lptr_d nD)
-{
-    // B_ is a reference argument of a non-inlined function, i.e. memory: a use inside a loop would be a flat load with its
-    // wait (the sixteen sweeps of a pivot tile each paid one) -- a register copy, taken once
-    const Blk B{B_.tid, uni(B_.nthr), B_.lane, uni(B_.wave), uni(B_.nwave), B_.red, B_.ired, uni_ptr(B_.pool), uni(B_.pool_n)};
-    const int ld = W.ld;
-    const gptr_d Sig = as_global_rw(W.Sig);
-    const int nT = (M + 15) >> 4, Mp = nT * 16;
-    const lptr_d nD2 = nD + 16 * 17;                         // second copy for the pivot sweeps
-    const int l15 = B.lane & 15, l4 = B.lane >> 4;
-    for (int tk = 0; tk < nT; tk++) {
-        const int k0 = tk * 16;
-        __syncthreads();
-        PHX_BEGIN(t_piv);
-        if (B.tid < 256) {                                   // pivot block (identity-padded)
-            const int r = B.tid & 15, c = B.tid >> 4, gi = k0 + r, gj = k0 + c;
-            double v;
-            if (gi < M && gj < M) { const int hi = gi > gj ? gi : gj, lo = gi > gj ? gj : gi; v = Sig[(size_t)lo * ld + hi]; }
-            else v = (gi == gj) ? 1.0 : 0.0;
-            nD[r * 17 + c] = v;
-        }
-        __syncthreads();
-        {   // scalar sweeps inside the block, ping-pong between two copies: one barrier per sweep, one division per
-            // element (numerator chosen first: the operations of the four cases of gm_spd_inverse_scalar); a pivot that
-            // is not positive is noticed by every thread alike and acted upon after the sweeps
-            bool bad = false;
-            const int r = B.tid & 15, c = (B.tid >> 4) & 15;
-#pragma unroll
-            for (int s = 0; s < 16; s++) {
-                const lptr_d src = (s & 1) ? nD2 : nD, dst = (s & 1) ? nD : nD2;
-                const double d = src[s * 17 + s], prs = src[r * 17 + s], psc = src[s * 17 + c], v = src[r * 17 + c];
-                bad |= !(d > 0);
-                const bool rs = r == s, cs = c == s;
-                const double num = rs ? (cs ? -1.0 : psc) : (cs ? prs : prs * psc);
-                const double t = num / d;
-                if (B.tid < 256) dst[r * 17 + c] = (rs || cs) ? t : v - t;
-                __syncthreads();
-            }
-            if (bad) return 1;
-        }                                                     // 16 sweeps: the result is back in nD
-        PHX_END(t_piv, PH_INV_PIVOT);
-        PHX_BEGIN(t_tn);
-        // Tn[i][r] = sum_s A(i, k0+s) * nD[s][r] for rows outside the block (zero inside / padding): one 16 x 16 x 16
-        // product per row tile on the matrix cores (four chained ops = the same k-ascending fma chain a scalar loop
-        // runs, tools/ubench/mfma_f64_order.hip); rows <-> i, columns <-> r
-        for (int ti = B.wave; ti < nT; ti += B.nwave) {
-            const int i = ti * 16 + l15;
-            const bool live = i < M && (i < k0 || i >= k0 + 16);
-            d4 acc = d4{0, 0, 0, 0};
-            double av[4], bw[4];
-#pragma unroll
-            for (int kk = 0; kk < 4; kk++) {
-                const int kc = k0 + kk * 4 + l4;
-                double v = 0;
-                if (live && kc < M) v = (i > kc) ? Sig[(size_t)kc * ld + i] : Sig[(size_t)i * ld + kc];
-                av[kk] = v;
-                bw[kk] = nD[(kk * 4 + l4) * 17 + l15];
-            }
-#pragma unroll
-            for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bw[kk], acc, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; r++) Tn[(size_t)(ti * 16 + l4 + 4 * r) * INV_TP + l15] = acc[r];
-        }
-        __syncthreads();
-        PHX_END(t_tn, PH_INV_TN);
-        // A22 += Tn * A21'  on the lower-triangle tiles that do not touch the pivot block.
-        // MFMA rows <-> j (column of A), MFMA columns <-> i (row of A): stores are contiguous in i.
-        // The tiles form a triangle over the nT - 1 non-pivot tile indices; tile number q = a (a + 1) / 2 + b
-        // (b <= a) goes to wave q mod nwave.  Each wave handles INV_TT of its tiles per trip so that their loads
-        // are in flight together (a tile on its own is one load -> matrix op -> store latency chain).
-        {
-            // The work is cut into runs of up to INV_RUN tiles down one tile column b (same 16 columns j of A,
-            // consecutive row tiles a >= b): the A21' operand depends on b only and is loaded once per run, which
-            // takes a third off the bytes a tile moves -- this phase is bound by the CU's path to L2, not by the
-            // matrix cores.  Runs are dealt to the waves round-robin; INV_TT tiles of a run are in flight together.
-            const int n1 = nT - 1;
-            int cnt = 0;
-            for (int b = 0; b < n1; b++) {
-                const int tj = b < tk ? b : b + 1;                  // skip the pivot tile row / column
-                for (int a0 = b; a0 < n1; a0 += INV_RUN) {
-                    if ((cnt++) % B.nwave != B.wave) continue;
-                    const int a1 = a0 + INV_RUN < n1 ? a0 + INV_RUN : n1;
-                    const int jrow = tj * 16 + l15;
-                    double av[4];
-#pragma unroll
-                    for (int kk = 0; kk < 4; kk++) {
-                        const int kc = k0 + kk * 4 + l4;
-                        double a_ = 0;
-                        if (jrow < M && kc < M) a_ = (jrow > kc) ? Sig[(size_t)kc * ld + jrow] : Sig[(size_t)jrow * ld + kc];
-                        av[kk] = a_;
-                    }
-                    for (int a = a0; a < a1; a += INV_TT) {
-                        d4 acc[INV_TT];
-                        double bv[INV_TT][4];
-#pragma unroll
-                        for (int z = 0; z < INV_TT; z++) {
-                            const int az = a + z < a1 ? a + z : a1 - 1;
-                            const int ti = az < tk ? az : az + 1;
-                            const int icol = ti * 16 + l15;
-#pragma unroll
-                            for (int r = 0; r < 4; r++) {
-                                const int j = tj * 16 + l4 + 4 * r;
-                                acc[z][r] = (icol < M && j < M) ? Sig[(size_t)j * ld + icol] : 0.0;
-                            }
-#pragma unroll
-                            for (int kk = 0; kk < 4; kk++) bv[z][kk] = Tn[(size_t)icol * INV_TP + kk * 4 + l4];
-                        }
-#pragma unroll
-                        for (int z = 0; z < INV_TT; z++)
-#pragma unroll
-                            for (int kk = 0; kk < 4; kk++) acc[z] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[z][kk], acc[z], 0, 0, 0);
-#pragma unroll
-                        for (int z = 0; z < INV_TT; z++) {
-                            if (a + z < a1) {
-                                const int ti = a + z < tk ? a + z : a + z + 1;
-                                const int icol = ti * 16 + l15;
-#pragma unroll
-                                for (int r = 0; r < 4; r++) {
-                                    const int j = tj * 16 + l4 + 4 * r;
-                                    if (icol < M && j < M) Sig[(size_t)j * ld + icol] = acc[z][r];
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        // pivot column panel <- A21 A11^-1 = -Tn, pivot block <- -A11^-1
-        for (int e = B.tid; e < Mp * 16; e += B.nthr) {
-            const int i = e >> 4, r = e & 15, kc = k0 + r;
-            if (i >= M || kc >= M || (i >= k0 && i < k0 + 16)) continue;
-            const double v = -Tn[(size_t)i * INV_TP + r];
-            if (i > kc) Sig[(size_t)kc * ld + i] = v; else Sig[(size_t)i * ld + kc] = v;
-        }
-        if (B.tid < 256) {
-            const int r = B.tid & 15, c = B.tid >> 4;
-            if (k0 + r < M && k0 + c < M) Sig[(size_t)(k0 + c) * ld + k0 + r] = nD[r * 17 + c];
-        }
-    }
-    __syncthreads();
-    for (int j = B.wave; j < M; j += B.nwave)
-        for (int i = j + B.lane; i < M; i += 64) {
-            const double v = -Sig[(size_t)j * ld + i];
-            Sig[(size_t)j * ld + i] = v;
-            Sig[(size_t)i * ld + j] = v;
-        }
-    __syncthreads();
-    return 0;
-}
-
 // ---- two pivot blocks per trip through memory ---------------------------------------------------------------
 // The trailing update of the blocked sweep above is bound by the CU's path to L2, not by the matrix cores: a tile is
 // loaded, takes four matrix ops and is stored again, once per pivot block.  Here two consecutive pivot blocks k, k+1
@@ -1358,23 +1204,42 @@ DEV void inv_av_pk(const gptr_d Pk, int Mp, int tj, int l15, int l4, double (&av
 #pragma unroll
     for (int kk = 0; kk < 4; kk++) av[kk] = Pk[(size_t)(kk * 4 + l4) * Mp + tj * 16 + l15];
 }
-// One run of the trailing update: the tiles (ti = rows(a), tj) for a in [a0, a1), INV_TT of them in flight together.
+// One run of the trailing update: the tiles (ti = rows(a), tj) for a in [a0, a1), INV_TT of them per trip.
 // NS = 2: A += Tn0 av0' then A += Tn1 av1' (two pivot blocks in one trip); NS = 1: the second pair only.
-template <int NS, class Rows>
+// The tiles of the NEXT trip are requested before the matrix ops of this one are issued (a second set of registers), as
+// raw values from clamped addresses -- an unguarded load per element: a guarded one becomes a branch and a full wait
+// each -- and the padding is masked to zero where the values are taken over, one trip later.
+// (Measured, tools/ubench/inverse_rate.py: this phase is bound by the tile LOADS -- ~17 GB/s per CU whatever the number of
+// tiles per trip (2, 4), the issue order of stores and loads, with or without the stores, with 8 or 256 workgroups
+// running: what a CU's outstanding-miss capacity delivers at ~2 us per access; a rank-16 update per trip is 2 flop per
+// byte, i.e. 21 % of the matrix peak at 640 - 1000 columns.  The request-ahead is worth 6 %, two pivot blocks per trip
+// 25 - 30 %; the register form removes the phase.)
+template <int NS, class Rows, class TP>
 DEV void inv_run(const gptr_d Sig, int ld, int M, int tj, int a0, int a1, Rows rows, const double (&av0)[4], const double (&av1)[4],
-                 const lptr_d Tn0, const lptr_d Tn1, int l15, int l4)
+                 const TP Tn0, const TP Tn1, int l15, int l4)
 {
+    d4 nxt[INV_TT];
+#define INV_LOAD_TILES(at)                                                                                           \
+    _Pragma("unroll") for (int z = 0; z < INV_TT; z++) {                                                             \
+        const int ti = rows((at) + z < a1 ? (at) + z : a1 - 1);                                                      \
+        const int icol = ti * 16 + l15, ic = icol < M ? icol : M - 1;                                                \
+        _Pragma("unroll") for (int r = 0; r < 4; r++) {                                                              \
+            const int j = tj * 16 + l4 + 4 * r, jc = j < M ? j : M - 1;                                              \
+            nxt[z][r] = Sig[(size_t)jc * ld + ic];                                                                   \
+        }                                                                                                            \
+    }
+    INV_LOAD_TILES(a0)
     for (int a = a0; a < a1; a += INV_TT) {
         d4 acc[INV_TT];
         double bv0[INV_TT][4], bv1[INV_TT][4];
 #pragma unroll
         for (int z = 0; z < INV_TT; z++) {
-            const int ti = rows(a + z < a1 ? a + z : a1 - 1);
-            const int icol = ti * 16 + l15;
+            const int icol = rows(a + z < a1 ? a + z : a1 - 1) * 16 + l15;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const int j = tj * 16 + l4 + 4 * r;
-                acc[z][r] = (icol < M && j < M) ? Sig[(size_t)j * ld + icol] : 0.0;
+                double v = nxt[z][r];
+                asm volatile("" : "+v"(v));                        // the load stays where it was issued
+                acc[z][r] = (icol < M && tj * 16 + l4 + 4 * r < M) ? v : 0.0;
             }
 #pragma unroll
             for (int kk = 0; kk < 4; kk++) {
@@ -1382,6 +1247,7 @@ DEV void inv_run(const gptr_d Sig, int ld, int M, int tj, int a0, int a1, Rows r
                 bv1[z][kk] = Tn1[(size_t)icol * INV_TP + kk * 4 + l4];
             }
         }
+        if (a + INV_TT < a1) { INV_LOAD_TILES(a + INV_TT) }
         if (NS == 2) {
 #pragma unroll
             for (int z = 0; z < INV_TT; z++)
@@ -1404,7 +1270,121 @@ DEV void inv_run(const gptr_d Sig, int ld, int M, int tj, int a0, int a1, Rows r
             }
         }
     }
+#undef INV_LOAD_TILES
 }
+// TP: where the M x 16 panel Tn lives -- LDS while it fits (M <= 1040 with the 152 KB pool), else the fit's own
+// scratch in HBM (W.Tn, L2-resident: 2048 x 18 doubles = 295 KB); the two 16 x 17 pivot blocks are always in LDS.
+template <class TP>
+DEVNI int gm_spd_inverse_blocked(const Blk &NOALIAS B_, const GmWork &NOALIAS W, int M, long long *phx, const TP Tn, const lptr_d nD)
+{
+    // B_ is a reference argument of a non-inlined function, i.e. memory: a use inside a loop would be a flat load with its
+    // wait (the sixteen sweeps of a pivot tile each paid one) -- a register copy, taken once
+    const Blk B{B_.tid, uni(B_.nthr), B_.lane, uni(B_.wave), uni(B_.nwave), B_.red, B_.ired, uni_ptr(B_.pool), uni(B_.pool_n)};
+    const int ld = W.ld;
+    const gptr_d Sig = as_global_rw(W.Sig);
+    const int nT = (M + 15) >> 4, Mp = nT * 16;
+    const lptr_d nD2 = nD + 16 * 17;                         // second copy for the pivot sweeps
+    const int l15 = B.lane & 15, l4 = B.lane >> 4;
+    for (int tk = 0; tk < nT; tk++) {
+        const int k0 = tk * 16;
+        __syncthreads();
+        PHX_BEGIN(t_piv);
+        if (B.tid < 256) {                                   // pivot block (identity-padded)
+            const int r = B.tid & 15, c = B.tid >> 4, gi = k0 + r, gj = k0 + c;
+            double v;
+            if (gi < M && gj < M) { const int hi = gi > gj ? gi : gj, lo = gi > gj ? gj : gi; v = Sig[(size_t)lo * ld + hi]; }
+            else v = (gi == gj) ? 1.0 : 0.0;
+            nD[r * 17 + c] = v;
+        }
+        __syncthreads();
+        {   // scalar sweeps inside the block, ping-pong between two copies: one barrier per sweep, one division per
+            // element (numerator chosen first: the operations of the four cases of gm_spd_inverse_scalar); a pivot that
+            // is not positive is noticed by every thread alike and acted upon after the sweeps
+            bool bad = false;
+            const int r = B.tid & 15, c = (B.tid >> 4) & 15;
+#pragma unroll
+            for (int s = 0; s < 16; s++) {
+                const lptr_d src = (s & 1) ? nD2 : nD, dst = (s & 1) ? nD : nD2;
+                const double d = src[s * 17 + s], prs = src[r * 17 + s], psc = src[s * 17 + c], v = src[r * 17 + c];
+                bad |= !(d > 0);
+                const bool rs = r == s, cs = c == s;
+                const double num = rs ? (cs ? -1.0 : psc) : (cs ? prs : prs * psc);
+                const double t = num / d;
+                if (B.tid < 256) dst[r * 17 + c] = (rs || cs) ? t : v - t;
+                __syncthreads();
+            }
+            if (bad) return 1;
+        }                                                     // 16 sweeps: the result is back in nD
+        PHX_END(t_piv, PH_INV_PIVOT);
+        PHX_BEGIN(t_tn);
+        // Tn[i][r] = sum_s A(i, k0+s) * nD[s][r] for rows outside the block (zero inside / padding): one 16 x 16 x 16
+        // product per row tile on the matrix cores (four chained ops = the same k-ascending fma chain a scalar loop
+        // runs, tools/ubench/mfma_f64_order.hip); rows <-> i, columns <-> r
+        for (int ti = B.wave; ti < nT; ti += B.nwave) {
+            const int i = ti * 16 + l15;
+            const bool live = i < M && (i < k0 || i >= k0 + 16);
+            d4 acc = d4{0, 0, 0, 0};
+            double av[4], bw[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                const int kc = k0 + kk * 4 + l4;
+                double v = 0;
+                if (live && kc < M) v = (i > kc) ? Sig[(size_t)kc * ld + i] : Sig[(size_t)i * ld + kc];
+                av[kk] = v;
+                bw[kk] = nD[(kk * 4 + l4) * 17 + l15];
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bw[kk], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; r++) Tn[(size_t)(ti * 16 + l4 + 4 * r) * INV_TP + l15] = acc[r];
+        }
+        __syncthreads();
+        PHX_END(t_tn, PH_INV_TN);
+        // A22 += Tn * A21'  on the lower-triangle tiles that do not touch the pivot block.
+        // MFMA rows <-> j (column of A), MFMA columns <-> i (row of A): stores are contiguous in i.
+        // The tiles form a triangle over the nT - 1 non-pivot tile indices, cut into runs of up to INV_RUN tiles down one
+        // tile column b (same 16 columns j of A, consecutive row tiles a >= b): the A21' operand depends on b only and is
+        // loaded once per run.  Runs are dealt to the waves round-robin (inv_run: INV_TT tiles per trip, the next trip's
+        // tiles requested ahead).
+        {
+            const int n1 = nT - 1;
+            const auto skip1 = [tk](int c) { return c < tk ? c : c + 1; };   // skip the pivot tile row / column
+            const double zero4[4] = {0, 0, 0, 0};
+            int cnt = 0;
+            for (int b = 0; b < n1; b++) {
+                const int tj = skip1(b);
+                for (int a0 = b; a0 < n1; a0 += INV_RUN) {
+                    if ((cnt++) % B.nwave != B.wave) continue;
+                    double av[4];
+                    inv_av_sig(Sig, ld, M, tj, k0, l15, l4, av);
+                    inv_run<1>(Sig, ld, M, tj, a0, a0 + INV_RUN < n1 ? a0 + INV_RUN : n1, skip1, zero4, av, Tn, Tn, l15, l4);
+                }
+            }
+        }
+        __syncthreads();
+        // pivot column panel <- A21 A11^-1 = -Tn, pivot block <- -A11^-1
+        for (int e = B.tid; e < Mp * 16; e += B.nthr) {
+            const int i = e >> 4, r = e & 15, kc = k0 + r;
+            if (i >= M || kc >= M || (i >= k0 && i < k0 + 16)) continue;
+            const double v = -Tn[(size_t)i * INV_TP + r];
+            if (i > kc) Sig[(size_t)kc * ld + i] = v; else Sig[(size_t)i * ld + kc] = v;
+        }
+        if (B.tid < 256) {
+            const int r = B.tid & 15, c = B.tid >> 4;
+            if (k0 + r < M && k0 + c < M) Sig[(size_t)(k0 + c) * ld + k0 + r] = nD[r * 17 + c];
+        }
+    }
+    __syncthreads();
+    for (int j = B.wave; j < M; j += B.nwave)
+        for (int i = j + B.lane; i < M; i += 64) {
+            const double v = -Sig[(size_t)j * ld + i];
+            Sig[(size_t)j * ld + i] = v;
+            Sig[(size_t)i * ld + j] = v;
+        }
+    __syncthreads();
+    return 0;
+}
+
 DEVNI int gm_spd_inverse_paired(const Blk &NOALIAS B_, const GmWork &NOALIAS W, int M, long long *phx)
 {
     // B_ is a reference argument of a non-inlined function, i.e. memory: a use inside a loop would be a flat load with its

@@ -65,3 +65,18 @@ def test_shard_cells_is_a_partition_and_cost_interleaved():
     # every rank sees the whole lambda range (cost mix), not a contiguous slab
     for p in parts:
         assert lam[p].min() < 0.1 and lam[p].max() > 0.9
+
+
+def test_shard_cells_spreads_every_alpha_column_on_a_rectangular_grid():
+    """20 alphas x 100 lambdas over 2, 4, 5, 8 ranks: every rank gets its share of every alpha column (the heavy fits sit on one
+    of them), within one cell; counts per rank within two cells of each other."""
+    from pareben_amd.dist import shard_cells
+    alpha = np.tile(np.linspace(1, 0.05, 20), 100)
+    lam = np.repeat(np.exp(np.linspace(2, -5, 100)), 20)
+    for w in (2, 4, 5, 8):
+        parts = [shard_cells(alpha, lam, r, w) for r in range(w)]
+        assert sorted(np.concatenate(parts).tolist()) == list(range(2000))
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 2
+        for a in np.unique(alpha):
+            per = [int((alpha[p] == a).sum()) for p in parts]
+            assert max(per) - min(per) <= 1, (w, a, per)

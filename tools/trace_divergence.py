@@ -7,7 +7,7 @@ order-free XOR hashes of S_in, Q_in and (Sigma, mu) after the iteration.
     python tools/trace_divergence.py run <table> <cell> <fold> <backend> <out.npy>     backend: oracle | emul | gpu | gpu-strict
     python tools/trace_divergence.py cmp <a.npy> <b.npy>
 
-`oracle` = oracle/liboracle.so (netlib order, reproduces real R to 1e-15 on these fits), `emul` = the device source
+`oracle` = oracle/liboracle.so (netlib order; reproduces real R to 1e-15 on non-chaotic fits and on about half of the chaotic ones), `emul` = the device source
 compiled for the CPU (tests/emul), `gpu` = pareben_fit_gaussian on cuda:0 (default summation order), `gpu-strict` =
 the same with PAREBEN_STRICT_ORDER=1.  Tables: subset5356 | yeast | looser13248 (tests/golden)."""
 import ctypes as C
