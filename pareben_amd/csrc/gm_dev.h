@@ -575,6 +575,39 @@ DEVNI void gm_sq_update(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const Gm
 // b_i = fb(i).  On the device both vectors are staged in LDS (at `scr`, 2 M doubles) and each wave keeps four
 // column chunks of b in registers while it walks its rows, so the only memory traffic is the coalesced
 // read-modify-write of Sigma with four loads in flight per wave; one fma per element either way.
+// one pass of gm_rank1 over CP column chunks of 64 starting at column i0 (compile-time chunk count: straight-line loads)
+template <int CP>
+DEV void gm_rank1_pass(const gptr_d Sg, int ld, int M, const lptr_d la, const lptr_d lb, int i0, int wave, int nwave)
+{
+    double br[CP];
+#pragma unroll
+    for (int c = 0; c < CP; c++) { const int i = i0 + c * BLK_LANES; br[c] = i < M ? lb[i] : 0.0; }
+    for (int j = wave; j < M; j += 2 * nwave) {
+        const int j2 = j + nwave;
+        const bool two = j2 < M;
+        const int j2c = two ? j2 : j;
+        const double f0 = la[j], f1 = two ? la[j2] : 0.0;
+        double s0[CP], s1[CP];
+        // unguarded loads from clamped addresses (a guarded load becomes a branch and a full wait per element); the values
+        // of lanes past the block are never stored
+#pragma unroll
+        for (int c = 0; c < CP; c++) {
+            const int i = i0 + c * BLK_LANES, ic = i < M ? i : M - 1;
+            s0[c] = Sg[(size_t)j * ld + ic];
+            s1[c] = Sg[(size_t)j2c * ld + ic];
+        }
+#pragma unroll
+        for (int c = 0; c < CP; c++) {
+            const int i = i0 + c * BLK_LANES;
+            double v0 = s0[c], v1 = s1[c];
+            asm volatile("" : "+v"(v0), "+v"(v1));              // the loads stay where they were issued
+            if (i < M) {
+                Sg[(size_t)j * ld + i] = v0 + f0 * br[c];
+                if (two) Sg[(size_t)j2 * ld + i] = v1 + f1 * br[c];
+            }
+        }
+    }
+}
 template <class FA, class FB>
 DEV void gm_rank1(const Blk &NOALIAS B, const GmWork &NOALIAS W, int M, double *scr, FA fa, FB fb)
 {
@@ -585,34 +618,15 @@ DEV void gm_rank1(const Blk &NOALIAS B, const GmWork &NOALIAS W, int M, double *
     blk_sync(B);
     const gptr_d Sg = as_global_rw(W.Sig);
     const int lane = B.lane, wave = B.wave, nwave = B.nwave;
-    // up to 8 column chunks of 64 per pass (balanced over the passes), two rows per trip: 16 loads in flight
-    const int NC = (M + BLK_LANES - 1) / BLK_LANES, npass = (NC + 7) >> 3, cpp = (NC + npass - 1) / npass;
-    for (int p = 0; p < npass; p++) {
-        const int i0 = p * cpp * BLK_LANES + lane;
-        double br[8];
-#pragma unroll
-        for (int c = 0; c < 8; c++) { const int i = i0 + c * BLK_LANES; br[c] = (c < cpp && i < M) ? lb[i] : 0.0; }
-        for (int j = wave; j < M; j += 2 * nwave) {
-            const int j2 = j + nwave;
-            const bool two = j2 < M;
-            const double f0 = la[j], f1 = two ? la[j2] : 0.0;
-            double s0[8], s1[8];
-#pragma unroll
-            for (int c = 0; c < 8; c++) {
-                const int i = i0 + c * BLK_LANES;
-                const bool on = c < cpp && i < M;
-                s0[c] = on ? Sg[(size_t)j * ld + i] : 0.0;
-                s1[c] = (on && two) ? Sg[(size_t)j2 * ld + i] : 0.0;
-            }
-#pragma unroll
-            for (int c = 0; c < 8; c++) {
-                const int i = i0 + c * BLK_LANES;
-                const bool on = c < cpp && i < M;
-                if (on) Sg[(size_t)j * ld + i] = s0[c] + f0 * br[c];
-                if (on && two) Sg[(size_t)j2 * ld + i] = s1[c] + f1 * br[c];
-            }
-        }
-    }
+    // column chunks of 64, up to 8 per pass, two rows per trip (up to 16 loads in flight); one fma per element whatever
+    // the split
+    const int NC = (M + BLK_LANES - 1) / BLK_LANES;
+    if (NC <= 1) gm_rank1_pass<1>(Sg, ld, M, la, lb, lane, wave, nwave);
+    else if (NC == 2) gm_rank1_pass<2>(Sg, ld, M, la, lb, lane, wave, nwave);
+    else if (NC == 3) gm_rank1_pass<3>(Sg, ld, M, la, lb, lane, wave, nwave);
+    else if (NC == 4) gm_rank1_pass<4>(Sg, ld, M, la, lb, lane, wave, nwave);
+    else if (NC <= 6) gm_rank1_pass<6>(Sg, ld, M, la, lb, lane, wave, nwave);
+    else for (int c0 = 0; c0 < NC; c0 += 8) gm_rank1_pass<8>(Sg, ld, M, la, lb, c0 * BLK_LANES + lane, wave, nwave);
 }
 
 // Gram row of feature u = the reference's BASIS_PHI row for that basis (MainEff.c:1608-1630):
@@ -1815,7 +1829,7 @@ DEV void gm_model_at2(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const GmWo
     const lptr_i lu = as_lds((int *)(B.pool + 2 * M));
     const gptr_cd X = as_global(F.X);
     double a0 = 0, a1 = 0;
-#pragma unroll 4
+#pragma unroll 8
     for (int j = 0; j < M; j++) {
         const size_t col = (size_t)lu[j] * N;
         const double c = lc[j], r = lr[j];
