@@ -115,6 +115,7 @@ DEVNI int bm_postmode(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const BmWo
     for (int it = 0; it < 25; it++) {
         const double elog = total;
         double gp = 0, hp = 0;
+        PHX2_BEGIN(pt0_);
         PAR(h, N) {
             double y = W.yv[h];
             if (S.v.epis) {                                    // NeFull.c:1042-1043
@@ -130,9 +131,13 @@ DEVNI int bm_postmode(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const BmWo
             gp += e; hp += b;
         }
         const double g0 = blk_sum(B, gp), h0 = blk_sum(B, hp);
+        PHX2_END(pt0_, 16);
+        PHX2_BEGIN(pt1_);
         bm_grad_hessian(B, F, W, M, N);                          // gradient entries 1.., Hessian Phi' diag(w) Phi + diag(A)
         if (B.tid == 0) { W.g[0] = g0; W.H[0] = h0; }
         blk_sync(B);
+        PHX2_END(pt1_, 17);
+        PHX2_BEGIN(pt2_);
         for (int j = B.wave; j < M; j += B.nwave)
             for (int i = B.lane; i < M; i += BLK_LANES) W.Sig[(size_t)j * ld + i] = W.H[(size_t)j * ld + i];
         blk_sync(B);
@@ -141,10 +146,12 @@ DEVNI int bm_postmode(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const BmWo
             if (gm_spd_inverse(B, G, M)) return 1;
         }
         blk_sync(B);
+        PHX2_END(pt2_, 18);
         int cp = 0;
         PAR(j, M) if ((j >= 1 || S.v.epis) && fabs(W.g[j]) < 1e-6) cp++;   // NeFull.c:1085-1099 counts the intercept's entry too
         const int cnt = blk_isum(B, cp);
         if (cnt == (S.v.epis ? M : M - 1)) break;
+        PHX2_BEGIN(pt3_);
         PAR(k, M) {
             double a = 0;
             for (int L = 0; L < M; L++) a += W.g[L] * W.Sig[(size_t)L * ld + k];
@@ -167,6 +174,10 @@ DEVNI int bm_postmode(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const BmWo
                 step = 0;
             }
         }
+        PHX2_END(pt3_, 19);
+#ifdef PAREBEN_PHASE_TIMERS
+        if (B.tid == 0) S.ph[20]++;                              // Newton iterations
+#endif
     }
     blk_sync(B);
     return 0;

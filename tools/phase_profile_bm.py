@@ -24,5 +24,7 @@ for k, n in names.items():
 print("  %-32s %6.2f %%" % ("other", 100 * (tot - ph[:, list(names)].sum()) / tot))
 print("  inside the weighted-rows pass of the full-stat calls: staging w.*Phi in LDS %.2f %%, matrix-core loop %.2f %%" % (
     100 * ph[:, 11].sum() / tot, 100 * ph[:, 8].sum() / tot))
+print("  inside the posterior mode: weights %.2f %%, gradient + Hessian %.2f %%, copy + inverse %.2f %%, step + line search %.2f %%; Newton iterations per full-stat %.2f" % (
+    100 * ph[:, 16].sum() / tot, 100 * ph[:, 17].sum() / tot, 100 * ph[:, 18].sum() / tot, 100 * ph[:, 19].sum() / tot, ph[:, 20].sum() / max(cnt.reshape(-1, cnt.shape[-1])[:, 5].sum(), 1)))
 c = cnt.reshape(-1, cnt.shape[-1])
 print("per fit: inner %.1f adds %.1f dels %.1f reest %.1f fullstats %.1f" % tuple(c[:, k].mean() for k in (1, 2, 3, 4, 5)))
