@@ -44,18 +44,21 @@ DEVNI void bm_phi_mu(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const BmWor
 // also bb-style single columns through `only` (>= 0: only that column, written to W.bb).
 // One 16-feature tile of bm_weighted_rows on the matrix cores, NCT column tiles of the staged block (compile-time: no
 // guards around the matrix ops), EXT = the staged block carries the residual column (statistics wanted).
+// xs: stride between consecutive samples of the lane's feature in the operand source -- 1 in the column-major design, K in
+// the sample-major copy (F.Xt), where the 16 features of a tile are one 128-byte line per sample: a load then touches 4
+// fully used lines instead of 16 quarter-used ones (the pass is bound by the CU's line requests, not by the matrix ops)
 template <int NCT, int EXT>
-DEV void bm_wr_tile(gptr_cd xa, lptr_d zb, lptr_d lw, int pitch, int Nu, int Nr, int l4, double (&out)[NCT][4], double &bbq_out)
+DEV void bm_wr_tile(gptr_cd xa, int xs, lptr_d zb, lptr_d lw, int pitch, int Nu, int Nr, int l4, double (&out)[NCT][4], double &bbq_out)
 {
     typedef double bd4 __attribute__((ext_vector_type(4)));
-    constexpr int RS = 8;
+    constexpr int RS = 8;                                      // steps per round (16 measured: no difference, config 3 261 vs 260 ms)
     bd4 acc[NCT];
 #pragma unroll
     for (int ct = 0; ct < NCT; ct++) acc[ct] = bd4{0, 0, 0, 0};
     double bbq = 0;
     double an[RS];
 #pragma unroll
-    for (int u = 0; u < RS; u++) { const int h = 4 * u + l4; an[u] = xa[h < Nu ? h : Nu - 1]; }
+    for (int u = 0; u < RS; u++) { const int h = 4 * u + l4; an[u] = xa[(size_t)(h < Nu ? h : Nu - 1) * xs]; }
     double bn[NCT];
 #pragma unroll
     for (int ct = 0; ct < NCT; ct++) bn[ct] = zb[ct * 16 * pitch];
@@ -64,7 +67,7 @@ DEV void bm_wr_tile(gptr_cd xa, lptr_d zb, lptr_d lw, int pitch, int Nu, int Nr,
 #pragma unroll
         for (int u = 0; u < RS; u++) ac[u] = (h0 + 4 * u + l4 < Nu) ? an[u] : 0.0;
 #pragma unroll
-        for (int u = 0; u < RS; u++) { const int h = h0 + 4 * RS + 4 * u + l4; an[u] = xa[h < Nu ? h : Nu - 1]; }
+        for (int u = 0; u < RS; u++) { const int h = h0 + 4 * RS + 4 * u + l4; an[u] = xa[(size_t)(h < Nu ? h : Nu - 1) * xs]; }
 #pragma unroll
         for (int u = 0; u < RS; u++) {
             const int hs = h0 + 4 * u;                             // wave-uniform
@@ -121,6 +124,7 @@ DEVNI int bm_weighted_rows(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const
         if (pcm >= 16) {
             const lptr_d Z = as_lds(uni_ptr(B.pool));          // [column][pitch]
             const gptr_cd gX = as_global(uni_ptr(F.X)), gw = as_global(uni_ptr(W.w)), ge = as_global(uni_ptr(W.e));
+            const gptr_cd gXt = as_global(uni_ptr(F.Xt));              // sample-major copy of the design (CV contexts), or null
             const gptr_cd gsc = as_global(uni_ptr(F.scale));
             const gptr_d gBP = as_global_rw(uni_ptr(W.BP)), gbb = as_global_rw(uni_ptr(W.bb)), gze = as_global_rw(uni_ptr(W.aroot));
             const int lane = B.lane, wave = uni(B.wave), nwave = uni(B.nwave), tid = B.tid, nthr = uni(B.nthr);
@@ -147,15 +151,17 @@ DEVNI int bm_weighted_rows(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const
                 PHX_BEGIN(t_mm);
                 for (int ft = wave; ft * 16 < Ku; ft += nwave) {
                     const int il = ft * 16 + l15;
-                    const gptr_cd xa = gX + (size_t)(il < Ku ? il : Ku - 1) * Nu;
+                    const int ilc = il < Ku ? il : Ku - 1;
+                    const gptr_cd xa = gXt ? gXt + ilc : gX + (size_t)ilc * Nu;
+                    const int xs = gXt ? Ku : 1;
                     const lptr_d zb = Z + l15 * pitch + l4;
                     double acc[MAXCT][4];
                     double bbq = 0;
 #define BM_WR_CASE(n)                                                                                                   \
                     case n: {                                                                                           \
                         double o[n][4];                                                                                 \
-                        if (ext) bm_wr_tile<n, 1>(xa, zb, lw, pitch, Nu, Nr, l4, o, bbq);                               \
-                        else bm_wr_tile<n, 0>(xa, zb, lw, pitch, Nu, Nr, l4, o, bbq);                                   \
+                        if (ext) bm_wr_tile<n, 1>(xa, xs, zb, lw, pitch, Nu, Nr, l4, o, bbq);                           \
+                        else bm_wr_tile<n, 0>(xa, xs, zb, lw, pitch, Nu, Nr, l4, o, bbq);                               \
                         _Pragma("unroll") for (int ct = 0; ct < n; ct++) _Pragma("unroll") for (int r = 0; r < 4; r++) acc[ct][r] = o[ct][r]; \
                     } break;
                     switch (nct) { BM_WR_CASE(1) BM_WR_CASE(2) BM_WR_CASE(3) default: BM_WR_CASE(4) }

@@ -1025,7 +1025,7 @@ static int ctx_create_impl(pareben_ctx **out, int device, const double *basis, i
         CK(dmalloc(&H.scale, KF)); CK(dmalloc(&H.rscale, KF));
         CK(dmalloc(&H.bt0, KF)); CK(dmalloc(&H.cs, KF));
         CK(dmalloc(&H.ystat, (size_t)2));
-        if (c->strict) CK(dmalloc(&H.Xt, (size_t)H.N * KF));
+        if (c->strict || prior == PAREBEN_PRIOR_BINOMIAL) CK(dmalloc(&H.Xt, (size_t)H.N * KF));   // sample-major copy: strict-order mode; the binomial weighted-rows pass (bm_dev.h)
     }
     if (prior == PAREBEN_PRIOR_GAUSSIAN) {         // binomial: no Gram matrix (the weights change)
         // Full per-fold Gram matrices when they fit beside the fit workspaces; else one buffer of
@@ -1108,7 +1108,7 @@ static int prepare_folds(pareben_ctx *c)
         if (H.nte) hipLaunchKernelGGL(gather_kernel, dim3((H.nte + 255) / 256), dim3(256), 0, c->stream, c->d_y, H.d_te, H.nte, H.yte);
         hipLaunchKernelGGL(colstats_kernel, dim3(kf), dim3(256), 0, c->stream, H.X, H.y, H.N, H.scale, H.rscale, H.bt0, H.cs,
                            H.G ? c->d_phi : (double *)nullptr, p);
-        if (c->strict)                               // gm_strict.h: the design sample-major, and the norms in the reference's sequential order
+        if (H.Xt)                                    // the design sample-major (gm_strict.h; bm_weighted_rows)
             hipLaunchKernelGGL(transpose_kernel, dim3((kf + 31) / 32, (H.N + 31) / 32), dim3(256), 0, c->stream, H.X, H.N, kf, H.Xt);
         if (c->strict)
             hipLaunchKernelGGL(strict_scale_kernel, dim3((kf + 255) / 256), dim3(256), 0, c->stream, H.X, H.N, kf, H.scale, H.rscale);

@@ -23,8 +23,9 @@ struct FoldDev {
     double ymean;           // sum(y)/N                                       MainEff.c:145-147
     double varY;            // unbiased variance of y                         MainEff.c:152
     int N, nte;
-    const double *Xt;       // strict-order mode only (else null): the training design once more, sample-major (N x K, Xt[h*K + i]), so
-                            // that one lane per feature reads whole lines when it walks the samples in order (gm_strict.h)
+    const double *Xt;       // strict-order mode and binomial CV contexts (else null): the training design once more, sample-major
+                            // (N x K, Xt[h*K + i]), so that lanes holding consecutive features read whole lines (gm_strict.h; bm_dev.h: the
+                            // matrix-core operand of the weighted-rows pass)
     int n_main;             // columns 0 .. n_main-1 are main effects: PHI = x * (1/scale) (MainEff.c:1062-1065, :517-520); the pair
                             // columns behind them (epistasis) are formed by division, PHI = x / scale (Full2.c:544, :913)
 };
