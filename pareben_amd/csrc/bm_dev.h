@@ -316,6 +316,43 @@ DEVNI void bm_quad_features(const Blk &NOALIAS B, const FoldDev &NOALIAS F, cons
 DEV void bm_grad_hessian(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const BmWork &NOALIAS W, int M, int N)
 {
     const int ld = W.ld;
+        if (N <= 8 * 64) {
+            // a lane's share of e and w in registers; four model columns per trip, their 4 x 8 design loads issued together from
+            // clamped addresses (a column at a time, element by element through BM_PHI, every term paid its own chain of
+            // dependent loads: used[] -> scale[] -> X); a lane's sums run over its samples in order as before
+            const gptr_cd gX = as_global(uni_ptr(F.X)), ge = as_global(uni_ptr(W.e)), gw = as_global(uni_ptr(W.w));
+            const int lane = B.lane, wave = uni(B.wave), nwave = uni(B.nwave), Nu = uni(N), Mu = uni(M);
+            const bool dv = W.phi_div != 0;
+            double er[8], wr[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) { const int h = lane + 64 * k; er[k] = h < Nu ? ge[h] : 0.0; wr[k] = h < Nu ? gw[h] : 0.0; }
+            for (int j0 = 1 + wave; j0 < Mu; j0 += 4 * nwave) {
+                double xr[4][8], sc[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const int j = j0 + c * nwave, u = uni(W.used[(j < Mu ? j : j0) - 1]);
+                    sc[c] = dv ? F.scale[u] : F.rscale[u];
+                    const gptr_cd x = gX + (size_t)u * Nu;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) { const int h = lane + 64 * k; xr[c][k] = x[h < Nu ? h : Nu - 1]; }
+                }
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const int j = j0 + c * nwave;
+                    if (j < Mu) {
+                        double ga = 0, ha = 0;
+#pragma unroll
+                        for (int k = 0; k < 8; k++) {
+                            double v = xr[c][k];
+                            asm volatile("" : "+v"(v));
+                            if (lane + 64 * k < Nu) { const double ph = dv ? v / sc[c] : v * sc[c]; ga += er[k] * ph; ha += wr[k] * ph; }
+                        }
+                        ga = wave_sum(ga); ha = wave_sum(ha);
+                        if (lane == 0) { W.g[j] = ga - W.A[j - 1] * W.mu[j]; W.H[j] = ha; W.H[(size_t)j * ld] = ha; }
+                    }
+                }
+            }
+        } else
         for (int j = 1 + B.wave; j < M; j += B.nwave) {
             double ga = 0, ha = 0;
             for (int h = B.lane; h < N; h += 64) { const double ph = BM_PHI(j, h); ga += W.e[h] * ph; ha += W.w[h] * ph; }
@@ -409,8 +446,38 @@ DEV void bm_feature_stats(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const 
 // bb[i] = x_i' (w .* phi) / |x_i| for all features and tmp[p] = Phi_p' (w .* phi) for the model columns (bm_add)
 DEV void bm_add_products(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const BmWork &NOALIAS W, int K, int M, int N)
 {
-    // eight features per wave and reduction tree: their loads are in flight together (a feature at a time paid a memory
-    // round trip per feature); wave_sum8 pairs lanes exactly like wave_sum, so the sums are the same bits
+    // eight features per wave and reduction tree (wave_sum8 pairs lanes exactly like wave_sum, so the sums are the same
+    // bits).  Up to 512 samples a lane's share of w .* phi lives in registers and the 8 x 8 design loads of a trip are
+    // issued together from clamped addresses before the first product (a lane's sum still runs over its samples in
+    // order): a trip is one memory round trip instead of one per feature and sample group.
+    if (N <= 8 * 64) {
+        const gptr_cd gX = as_global(uni_ptr(F.X)), gbp = as_global(uni_ptr(W.bphi));
+        const int lane = B.lane, wave = uni(B.wave), nwave = uni(B.nwave);
+        N = uni(N); K = uni(K);
+        double bp[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const int h = lane + 64 * k; bp[k] = h < N ? gbp[h] : 0.0; }
+        for (int i0 = wave * 8; i0 < K; i0 += nwave * 8) {
+            double xr[8][8];
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const gptr_cd x = gX + (size_t)(i0 + c < K ? i0 + c : K - 1) * N;
+#pragma unroll
+                for (int k = 0; k < 8; k++) { const int h = lane + 64 * k; xr[c][k] = x[h < N ? h : N - 1]; }
+            }
+            double a[8];
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                double t = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) { double v = xr[c][k]; asm volatile("" : "+v"(v)); if (lane + 64 * k < N) t += v * bp[k]; }
+                a[c] = t;
+            }
+            wave_sum8(a, lane);
+            const int i = i0 + (lane >> 3);
+            if ((lane & 7) == 0 && i < K) W.bb[i] = a[0] / F.scale[i];
+        }
+    } else
     for (int i0 = B.wave * 8; i0 < K; i0 += B.nwave * 8) {
         double a[8];
 #pragma unroll
@@ -423,6 +490,42 @@ DEV void bm_add_products(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const B
         wave_sum8(a, B.lane);
         const int i = i0 + (B.lane >> 3);
         if ((B.lane & 7) == 0 && i < K) W.bb[i] = a[0] / F.scale[i];
+    }
+    if (N <= 8 * 64) {                                          // the same for the model columns, four per trip
+        const gptr_cd gX = as_global(uni_ptr(F.X)), gbp = as_global(uni_ptr(W.bphi));
+        const int lane = B.lane, wave = uni(B.wave), nwave = uni(B.nwave), Mu = uni(M);
+        const bool dv = W.phi_div != 0;
+        double bp[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const int h = lane + 64 * k; bp[k] = h < N ? gbp[h] : 0.0; }
+        for (int p0 = wave; p0 < Mu; p0 += 4 * nwave) {
+            double xr[4][8], sc[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int pp = p0 + c * nwave, pc = pp < Mu ? pp : p0;
+                const int u = pc >= 1 ? uni(W.used[pc - 1]) : 0;
+                sc[c] = dv ? F.scale[u] : F.rscale[u];
+                const gptr_cd x = gX + (size_t)u * N;
+#pragma unroll
+                for (int k = 0; k < 8; k++) { const int h = lane + 64 * k; xr[c][k] = x[h < N ? h : N - 1]; }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int pp = p0 + c * nwave;
+                if (pp < Mu) {
+                    double a = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        double v = xr[c][k];
+                        asm volatile("" : "+v"(v));
+                        if (lane + 64 * k < N) { const double ph = pp == 0 ? 1.0 : (dv ? v / sc[c] : v * sc[c]); a += ph * bp[k]; }
+                    }
+                    a = wave_sum(a);
+                    if (lane == 0) W.tmp[pp] = a;
+                }
+            }
+        }
+        return;
     }
     for (int p = B.wave; p < M; p += B.nwave) {
         double a = 0;
