@@ -40,6 +40,45 @@ DEVNI void bm_phi_mu(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const BmWor
     bm_phi_mu_plain(B, F, W, M, mu, out);
 }
 
+// t_i = sum_j BP[i][j] * vec[j] (j ascending: one fma chain per feature, the reference's loop order) for every feature i,
+// handed to f(i, t): the K x M mat-vec every action ends with.  A thread walks its own row of BP; the vector is staged in
+// LDS and the row entries are requested eight at a time from clamped addresses, so a row costs M / 8 memory round trips
+// instead of M (element by element through generic pointers every term waited for its own two loads).
+template <class Fn>
+DEV void bm_rows_dot(const Blk &NOALIAS B, const BmWork &NOALIAS W, int K, int M, const double *vec, Fn f)
+{
+    const lptr_d lv = as_lds(B.pool);
+    blk_sync(B);
+    PAR(j, M) lv[j] = vec[j];
+    blk_sync(B);
+    const gptr_cd gBP = as_global(W.BP);
+    const int ld = W.ld;
+    PAR(i, K) {
+        const gptr_cd bp = gBP + (size_t)i * ld;
+        double t = 0;
+        double nx[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) nx[c] = bp[c < M ? c : M - 1];
+        for (int j0 = 0; j0 < M; j0 += 8) {
+            double cur[8];
+#pragma unroll
+            for (int c = 0; c < 8; c++) cur[c] = nx[c];
+            if (j0 + 8 < M) {
+#pragma unroll
+                for (int c = 0; c < 8; c++) { const int j = j0 + 8 + c; nx[c] = bp[j < M ? j : M - 1]; }
+            }
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                double v = cur[c];
+                asm volatile("" : "+v"(v));
+                if (j0 + c < M) t += v * lv[j0 + c];
+            }
+        }
+        f(i, t);
+    }
+    blk_sync(B);
+}
+
 // BP[i][p] = sum_h x_i[h] w[h] Phi_p[h] / |x_i| for all features i and model columns p < M;
 // also bb-style single columns through `only` (>= 0: only that column, written to W.bb).
 // One 16-feature tile of bm_weighted_rows on the matrix cores, NCT column tiles of the staged block (compile-time: no

@@ -321,15 +321,12 @@ DEVNI void bm_add(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const BmWork &
     // rows against the OLD model columns: still current from the last full-stat pass / action unless the
     // weights changed in between (they only change in the posterior-mode step)
     if (S.bp_ok != M) bm_weighted_rows(B, F, W, K, M);
-    PAR(i, K) {
-        const double *bp = W.BP + (size_t)i * ld;
-        double t = 0;
-        for (int j = 0; j < M; j++) t += bp[j] * W.tp[j];
+    bm_rows_dot(B, W, K, M, W.tp, [&](int i, double t) {
         const double mc = W.bb[i] - t;
         W.Sin[i] = W.Sin[i] - mc * mc * sii;
         W.Qin[i] = W.Qin[i] - mui * mc;
         W.BP[(size_t)i * ld + M] = W.bb[i];                    // the new model column's weighted row entry
-    }
+    });
     S.bp_ok = M + 1;
     PAR(i, M) W.mu[i] += -mui * W.tp[i];
     for (int j = B.wave; j < M; j += B.nwave) {
@@ -362,14 +359,11 @@ DEVNI void bm_delete(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const BmWor
     const double mujj = W.mu[j1];
     const int gone = W.used[jj];
     if (S.bp_ok != M) bm_weighted_rows(B, F, W, K, M);
-    PAR(i, K) {
-        const double *bp = W.BP + (size_t)i * ld;
-        double t = 0;
-        for (int j = 0; j < M; j++) t += bp[j] * W.tp[j];
+    bm_rows_dot(B, W, K, M, W.tp, [&](int i, double t) {
         W.Sin[i] = W.Sin[i] + t * t / sjj;
         W.Qin[i] = W.Qin[i] + t * mujj / sjj;
         W.BP[(size_t)i * ld + j1] = W.BP[(size_t)i * ld + last];   // the last model column moves into the freed slot
-    }
+    });
     S.bp_ok = last;
     PAR(i, M) W.mu[i] = W.mu[i] - mujj * W.tp[i] / sjj;
     for (int j = B.wave; j < M; j += B.nwave) {
@@ -418,13 +412,10 @@ DEVNI void bm_reestimate(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const B
     PAR(i, M) W.tmp[i] = W.Sig[(size_t)j1 * ld + i];           // the updated row
     blk_sync(B);
     if (S.bp_ok != M) bm_weighted_rows(B, F, W, K, M);
-    PAR(i, K) {
-        const double *bp = W.BP + (size_t)i * ld;
-        double t = 0;
-        for (int j = 0; j < M; j++) t += bp[j] * W.tmp[j];
+    bm_rows_dot(B, W, K, M, W.tmp, [&](int i, double t) {
         W.Sin[i] = W.Sin[i] + t * t * kappa;
         W.Qin[i] = W.Qin[i] + mujj * kappa * t;
-    }
+    });
     blk_sync(B);
 }
 

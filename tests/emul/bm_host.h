@@ -6,6 +6,18 @@
 
 DEV void bm_phi_mu(const Blk &B, const FoldDev &F, const BmWork &W, int M, const double *mu, double *out) { bm_phi_mu_plain(B, F, W, M, mu, out); }
 
+// t_i = sum_j BP[i][j] * vec[j] (j ascending) for every feature i, handed to f(i, t)
+template <class Fn>
+DEV void bm_rows_dot(const Blk &B, const BmWork &W, int K, int M, const double *vec, Fn f)
+{
+    PAR(i, K) {
+        const double *bp = W.BP + (size_t)i * W.ld;
+        double t = 0;
+        for (int j = 0; j < M; j++) t += bp[j] * vec[j];
+        f(i, t);
+    }
+}
+
 // BP[i][p] = sum_h x_i[h] w[h] Phi_p[h] / |x_i| for all features i and model columns p < M;
 // also bb-style single columns through `only` (>= 0: only that column, written to W.bb).
 
