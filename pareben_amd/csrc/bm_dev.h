@@ -352,9 +352,101 @@ DEVNI void bm_quad_features(const Blk &NOALIAS B, const FoldDev &NOALIAS F, cons
 }
 
 // gradient entries 1 .. M-1 and the Hessian Phi' diag(w) Phi + diag(A) of one Newton step (NEmainEff.c:1890-1925)
+// The same with the model columns staged in LDS first (Phi_p sample-contiguous, odd pitch, zero beyond the last sample; the
+// weights behind them): one coalesced sweep of the M - 1 design columns by the whole workgroup, then the gradient sums and
+// the chains of matrix ops read LDS.  Straight from the design a tile pair is a chain of N / 4 dependent matrix ops whose
+// operands arrive eight steps at a time at 1 - 2 us a round (three waves busy, 38 us per call); from LDS it is bound by
+// the chain itself.  Same products, same association ((phi_j * w) * phi_k), same order over the samples: same bits.
+DEV bool bm_grad_hessian_lds(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const BmWork &NOALIAS W, int M, int N)
+{
+    typedef double bd4 __attribute__((ext_vector_type(4)));
+    const int Mm = uni(M) - 1, Nu = uni(N), Nr = (Nu + 3) & ~3, pitch = Nr + 1, ld = uni(W.ld);
+    if (Mm < 1 || Nu > 8 * 64 || Mm * pitch + Nr > uni(B.pool_n)) return false;
+    const lptr_d Z = as_lds(uni_ptr(B.pool)), lw = Z + Mm * pitch;
+    const gptr_cd gX = as_global(uni_ptr(F.X)), ge = as_global(uni_ptr(W.e)), gw = as_global(uni_ptr(W.w));
+    const int lane = B.lane, wave = uni(B.wave), nwave = uni(B.nwave), tid = B.tid, nthr = uni(B.nthr);
+    const bool dv = W.phi_div != 0;
+    blk_sync(B);
+    for (int c = wave; c < Mm; c += nwave) {                     // a wave per column: coalesced 512-byte loads
+        const int u = uni(W.used[c]);
+        const double sc = dv ? F.scale[u] : F.rscale[u];
+        const gptr_cd x = gX + (size_t)u * Nu;
+        for (int h = lane; h < pitch; h += 64) {
+            const double v = x[h < Nu ? h : Nu - 1];
+            Z[c * pitch + h] = h < Nu ? (dv ? v / sc : v * sc) : 0.0;
+        }
+    }
+    for (int h = tid; h < Nr; h += nthr) lw[h] = h < Nu ? gw[h] : 0.0;
+    blk_sync(B);
+    {   // gradient entries and first row / column of the Hessian: a lane's sums over its samples in order, then the wave tree
+        double er[8], wr[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const int h = lane + 64 * k; er[k] = h < Nu ? ge[h] : 0.0; wr[k] = h < Nu ? lw[h < Nr ? h : 0] : 0.0; }
+        for (int j = 1 + wave; j <= Mm; j += nwave) {
+            double ga = 0, ha = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int h = lane + 64 * k;
+                if (h < Nu) { const double ph = Z[(j - 1) * pitch + h]; ga += er[k] * ph; ha += wr[k] * ph; }
+            }
+            ga = wave_sum(ga); ha = wave_sum(ha);
+            if (lane == 0) { W.g[j] = ga - W.A[j - 1] * W.mu[j]; W.H[j] = ha; W.H[(size_t)j * ld] = ha; }
+        }
+    }
+    const int l15 = lane & 15, l4 = lane >> 4;
+    if (Mm >= 8) {                                               // 16 x 16 tiles, lower-triangle tile pairs dealt to the waves
+        const int nT = (Mm + 15) >> 4;
+        for (int q = wave; q < nT * (nT + 1) / 2; q += nwave) {
+            int tj = (int)((sqrt(8.0 * q + 1.0) - 1.0) * 0.5);
+            while ((tj + 1) * (tj + 2) / 2 <= q) tj++;
+            while (tj * (tj + 1) / 2 > q) tj--;
+            const int tk = q - tj * (tj + 1) / 2;
+            const int ja = tj * 16 + l15, kb = tk * 16 + l15;
+            const lptr_d za = Z + (ja < Mm ? ja : Mm - 1) * pitch + l4, zb = Z + (kb < Mm ? kb : Mm - 1) * pitch + l4;
+            const bool ona = ja < Mm, onb = kb < Mm;
+            bd4 acc = bd4{0, 0, 0, 0};
+            double pa = za[0], pb = zb[0], pw = lw[l4];
+            for (int h0 = 0; h0 < Nr; h0 += 4) {
+                const double ca = pa, cb = pb, cw = pw;
+                const int hn = h0 + 4 < Nr ? h0 + 4 : h0;         // next step's operands behind this step's matrix op
+                pa = za[hn]; pb = zb[hn]; pw = lw[hn + l4];
+                const double a = ona ? ca * cw : 0.0, b = onb ? cb : 0.0;   // samples beyond N are zero in Z
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int jm = tj * 16 + l4 + 4 * r, km = tk * 16 + l15;
+                if (jm < Mm && km < Mm && km <= jm) {
+                    double v = acc[r];
+                    if (jm == km) v += W.A[km];
+                    W.H[(size_t)(km + 1) * ld + jm + 1] = v; W.H[(size_t)(jm + 1) * ld + km + 1] = v;
+                }
+            }
+        }
+    } else {                                                     // few columns: one wavefront per (j, k) pair, the reference's triple product
+        const int np = Mm * (Mm + 1) / 2;
+        for (int q = wave; q < np; q += nwave) {
+            int j = (int)((sqrt(8.0 * q + 1.0) - 1.0) * 0.5);
+            while ((j + 1) * (j + 2) / 2 <= q) j++;
+            while (j * (j + 1) / 2 > q) j--;
+            const int k = q - j * (j + 1) / 2;                   // 0 <= k <= j < Mm
+            double a = 0;
+            for (int h = lane; h < Nu; h += 64) a += Z[j * pitch + h] * lw[h] * Z[k * pitch + h];
+            a = wave_sum(a);
+            if (lane == 0) {
+                if (j == k) a += W.A[k];
+                W.H[(size_t)(k + 1) * ld + j + 1] = a; W.H[(size_t)(j + 1) * ld + k + 1] = a;
+            }
+        }
+    }
+    blk_sync(B);
+    return true;
+}
+
 DEV void bm_grad_hessian(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const BmWork &NOALIAS W, int M, int N)
 {
     const int ld = W.ld;
+    if (bm_grad_hessian_lds(B, F, W, M, N)) return;
         if (N <= 8 * 64) {
             // a lane's share of e and w in registers; four model columns per trip, their 4 x 8 design loads issued together from
             // clamped addresses (a column at a time, element by element through BM_PHI, every term paid its own chain of
