@@ -86,8 +86,11 @@ DEV void bm_rows_dot(const Blk &NOALIAS B, const BmWork &NOALIAS W, int K, int M
 // xs: stride between consecutive samples of the lane's feature in the operand source -- 1 in the column-major design, K in
 // the sample-major copy (F.Xt), where the 16 features of a tile are one 128-byte line per sample: a load then touches 4
 // fully used lines instead of 16 quarter-used ones (the pass is bound by the CU's line requests, not by the matrix ops)
+// The operand is addressed as a wave-uniform base (scalar registers) plus a 32-bit byte offset per lane (xo: the lane's
+// feature, xs: bytes between consecutive samples), the form in which the memory pipe takes a load at full rate; the
+// design is far below 4 GB.
 template <int NCT, int EXT>
-DEV void bm_wr_tile(gptr_cd xa, int xs, lptr_d zb, lptr_d lw, int pitch, int Nu, int Nr, int l4, double (&out)[NCT][4], double &bbq_out)
+DEV void bm_wr_tile(gptr_cc xb, unsigned xo, unsigned xs, lptr_d zb, lptr_d lw, int pitch, int Nu, int Nr, int l4, double (&out)[NCT][4], double &bbq_out)
 {
     typedef double bd4 __attribute__((ext_vector_type(4)));
     constexpr int RS = 8;                                      // steps per round (16 measured: no difference, config 3 261 vs 260 ms)
@@ -97,7 +100,7 @@ DEV void bm_wr_tile(gptr_cd xa, int xs, lptr_d zb, lptr_d lw, int pitch, int Nu,
     double bbq = 0;
     double an[RS];
 #pragma unroll
-    for (int u = 0; u < RS; u++) { const int h = 4 * u + l4; an[u] = xa[(size_t)(h < Nu ? h : Nu - 1) * xs]; }
+    for (int u = 0; u < RS; u++) { const int h = 4 * u + l4; an[u] = *(gptr_cd)(xb + (xo + (unsigned)(h < Nu ? h : Nu - 1) * xs)); }
     double bn[NCT];
 #pragma unroll
     for (int ct = 0; ct < NCT; ct++) bn[ct] = zb[ct * 16 * pitch];
@@ -106,7 +109,7 @@ DEV void bm_wr_tile(gptr_cd xa, int xs, lptr_d zb, lptr_d lw, int pitch, int Nu,
 #pragma unroll
         for (int u = 0; u < RS; u++) ac[u] = (h0 + 4 * u + l4 < Nu) ? an[u] : 0.0;
 #pragma unroll
-        for (int u = 0; u < RS; u++) { const int h = h0 + 4 * RS + 4 * u + l4; an[u] = xa[(size_t)(h < Nu ? h : Nu - 1) * xs]; }
+        for (int u = 0; u < RS; u++) { const int h = h0 + 4 * RS + 4 * u + l4; an[u] = *(gptr_cd)(xb + (xo + (unsigned)(h < Nu ? h : Nu - 1) * xs)); }
 #pragma unroll
         for (int u = 0; u < RS; u++) {
             const int hs = h0 + 4 * u;                             // wave-uniform
@@ -191,16 +194,17 @@ DEVNI int bm_weighted_rows(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const
                 for (int ft = wave; ft * 16 < Ku; ft += nwave) {
                     const int il = ft * 16 + l15;
                     const int ilc = il < Ku ? il : Ku - 1;
-                    const gptr_cd xa = gXt ? gXt + ilc : gX + (size_t)ilc * Nu;
-                    const int xs = gXt ? Ku : 1;
+                    const gptr_cc xb = (gptr_cc)(gXt ? gXt : gX);
+                    const unsigned xo = gXt ? (unsigned)ilc * 8u : (unsigned)ilc * (unsigned)Nu * 8u;
+                    const unsigned xs = gXt ? (unsigned)Ku * 8u : 8u;
                     const lptr_d zb = Z + l15 * pitch + l4;
                     double acc[MAXCT][4];
                     double bbq = 0;
 #define BM_WR_CASE(n)                                                                                                   \
                     case n: {                                                                                           \
                         double o[n][4];                                                                                 \
-                        if (ext) bm_wr_tile<n, 1>(xa, xs, zb, lw, pitch, Nu, Nr, l4, o, bbq);                           \
-                        else bm_wr_tile<n, 0>(xa, xs, zb, lw, pitch, Nu, Nr, l4, o, bbq);                               \
+                        if (ext) bm_wr_tile<n, 1>(xb, xo, xs, zb, lw, pitch, Nu, Nr, l4, o, bbq);                       \
+                        else bm_wr_tile<n, 0>(xb, xo, xs, zb, lw, pitch, Nu, Nr, l4, o, bbq);                           \
                         _Pragma("unroll") for (int ct = 0; ct < n; ct++) _Pragma("unroll") for (int r = 0; r < 4; r++) acc[ct][r] = o[ct][r]; \
                     } break;
                     switch (nct) { BM_WR_CASE(1) BM_WR_CASE(2) BM_WR_CASE(3) default: BM_WR_CASE(4) }
