@@ -132,7 +132,7 @@ DEVNI int gm_spd_inverse_scalar(const Blk &NOALIAS B, const GmWork &NOALIAS W, i
 
 // Full statistics, MainEff.c:1209-1341 (Q3: gamma[0] is left alone).
 DEV void gm_fullstat(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const GmWork &NOALIAS W, int K, GmScalars &NOALIAS S,
-                     bool very_first)
+                     bool very_first, bool mu_current = false)
 {
     const int M = S.M, ld = W.ld;
     const double beta = S.beta;
@@ -142,14 +142,19 @@ DEV void gm_fullstat(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const GmWor
             W.Sig[0] = 1 / W.H[0];
         }
     }
-    PAR(l, M) W.v1[l] = W.bt[W.used[l]];                     // Phi' t
-    blk_sync(B);
-    PAR(i, M) {
-        double a = 0;
-        for (int j = 0; j < M; j++) a += W.v1[j] * W.Sig[(size_t)j * ld + i];
-        W.mu[i] = a * beta;
-        if (i >= 1) W.gam[i] = 1 - W.Sig[(size_t)i * ld + i] * W.A[i];
+    // mu = beta Sigma Phi't (:1266-1289).  mu_current: the caller comes straight from gm_final_update, which has just formed
+    // exactly this product from the same Sigma, Phi't and beta (same expression, same order: the same bits) -- the M^2 loop
+    // is not run a second time (nine of ten passes of a grid are reached that way)
+    if (!mu_current) {
+        PAR(l, M) W.v1[l] = W.bt[W.used[l]];                 // Phi' t
+        blk_sync(B);
+        PAR(i, M) {
+            double a = 0;
+            for (int j = 0; j < M; j++) a += W.v1[j] * W.Sig[(size_t)j * ld + i];
+            W.mu[i] = a * beta;
+        }
     }
+    PAR(i, M) if (i >= 1) W.gam[i] = 1 - W.Sig[(size_t)i * ld + i] * W.A[i];
     gm_fs_pad(B, W, M);                                       // matrix-core pass: exact zeros in the ragged 16-block (gm_dev.h)
     blk_sync(B);
     {
@@ -642,7 +647,7 @@ DEV int gm_inner(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const GmWork &N
             PH_END(PH_NOISE);
             if (fabs(dlb) > 1e-6) {
                 if (gm_final_update(B, F, W, K, S)) { S.status |= ST_CHOLESKY | ST_ABORT; return 1; }
-                if (sel != ACT_TERM) { S.pend.kind = 0; gm_fullstat(B, F, W, K, S, false); fs_done = true; }
+                if (sel != ACT_TERM) { S.pend.kind = 0; gm_fullstat(B, F, W, K, S, false, true); fs_done = true; }
             }
         }
         if (S.pend.kind) { PH_BEGIN(); gm_flush_pending(B, F, W, K, S); PH_END(PH_ACTION); }
