@@ -178,14 +178,24 @@ DEVNI int bm_weighted_rows(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const
                 const lptr_d lw = Z + pcm * pitch;                     // the weights, zero beyond the last sample
                 blk_sync(B);
                 PHX_BEGIN(t_st);
-                for (int e = tid; e < pn16 * pitch; e += nthr) {
-                    const int pc = e / pitch, h = e - pc * pitch;
-                    double v = 0.0;
-                    if (h < Nu) {
-                        if (pc < pn) v = gw[h] * BM_PHI(p0 + pc, h);
-                        else if (ext && pc == pn) v = ge[h];
+                // a wave per staged column: the column's feature id and norm are wave-uniform, the design column is read in
+                // whole lines (element by element every entry paid the chain used[] -> scale[] -> X and an integer division)
+                for (int pc = wave; pc < pn16; pc += nwave) {
+                    const int pm = p0 + pc;
+                    const bool model = pc < pn, resid = ext && pc == pn;
+                    const int u = (model && pm >= 1) ? uni(W.used[pm - 1]) : 0;
+                    const bool dvz = W.phi_div != 0;
+                    const double sc = dvz ? gsc[u] : F.rscale[u];
+                    const gptr_cd x = gX + (size_t)u * Nu;
+                    for (int h = lane; h < pitch; h += 64) {
+                        const int hc = h < Nu ? h : Nu - 1;
+                        double v = 0.0;
+                        if (h < Nu) {
+                            if (model) { const double xv = x[hc]; v = gw[hc] * (pm == 0 ? 1.0 : (dvz ? xv / sc : xv * sc)); }
+                            else if (resid) v = ge[hc];
+                        }
+                        Z[pc * pitch + h] = v;
                     }
-                    Z[e] = v;
                 }
                 if (ext) for (int h = tid; h < Nr; h += nthr) lw[h] = h < Nu ? gw[h] : 0.0;
                 blk_sync(B);
