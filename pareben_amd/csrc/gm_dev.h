@@ -1228,6 +1228,12 @@ DEV void inv_av_pk(const gptr_d Pk, int Mp, int tj, int l15, int l4, double (&av
 // running: what a CU's outstanding-miss capacity delivers at ~2 us per access; a rank-16 update per trip is 2 flop per
 // byte, i.e. 21 % of the matrix peak at 640 - 1000 columns.  The request-ahead is worth 6 %, two pivot blocks per trip
 // 25 - 30 %; the register form removes the phase.)
+// timing-only ablations of the trailing update (tools/ubench/inverse_rate.py with a -DINV_DIAG_* build; results are wrong)
+#ifdef INV_DIAG_NOLOAD
+#define INV_DIAG_LOAD(expr, jc, ic) (1e-3 * (double)((jc) + (ic)))
+#else
+#define INV_DIAG_LOAD(expr, jc, ic) (expr)
+#endif
 template <int NS, class Rows, class TP>
 DEV void inv_run(const gptr_d Sig, int ld, int M, int tj, int a0, int a1, Rows rows, const double (&av0)[4], const double (&av1)[4],
                  const TP Tn0, const TP Tn1, int l15, int l4)
@@ -1239,7 +1245,7 @@ DEV void inv_run(const gptr_d Sig, int ld, int M, int tj, int a0, int a1, Rows r
         const int icol = ti * 16 + l15, ic = icol < M ? icol : M - 1;                                                \
         _Pragma("unroll") for (int r = 0; r < 4; r++) {                                                              \
             const int j = tj * 16 + l4 + 4 * r, jc = j < M ? j : M - 1;                                              \
-            nxt[z][r] = Sig[(size_t)jc * ld + ic];                                                                   \
+            nxt[z][r] = INV_DIAG_LOAD(Sig[(size_t)jc * ld + ic], jc, ic);                                            \
         }                                                                                                            \
     }
     INV_LOAD_TILES(a0)
@@ -1279,7 +1285,11 @@ DEV void inv_run(const gptr_d Sig, int ld, int M, int tj, int a0, int a1, Rows r
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int j = tj * 16 + l4 + 4 * r;
+#ifdef INV_DIAG_NOSTORE
+                    if (icol < M && j < M && acc[z][r] == 1.2345e300) Sig[(size_t)j * ld + icol] = acc[z][r];
+#else
                     if (icol < M && j < M) Sig[(size_t)j * ld + icol] = acc[z][r];
+#endif
                 }
             }
         }
@@ -1327,7 +1337,9 @@ DEVNI int gm_spd_inverse_blocked(const Blk &NOALIAS B_, const GmWork &NOALIAS W,
                 if (B.tid < 256) dst[r * 17 + c] = (rs || cs) ? t : v - t;
                 __syncthreads();
             }
+#ifndef INV_DIAG_NOEXIT
             if (bad) return 1;
+#endif
         }                                                     // 16 sweeps: the result is back in nD
         PHX_END(t_piv, PH_INV_PIVOT);
         PHX_BEGIN(t_tn);
