@@ -1223,11 +1223,12 @@ DEV void inv_av_pk(const gptr_d Pk, int Mp, int tj, int l15, int l4, double (&av
 // The tiles of the NEXT trip are requested before the matrix ops of this one are issued (a second set of registers), as
 // raw values from clamped addresses -- an unguarded load per element: a guarded one becomes a branch and a full wait
 // each -- and the padding is masked to zero where the values are taken over, one trip later.
-// (Measured, tools/ubench/inverse_rate.py: this phase is bound by the tile LOADS -- ~17 GB/s per CU whatever the number of
-// tiles per trip (2, 4), the issue order of stores and loads, with or without the stores, with 8 or 256 workgroups
-// running: what a CU's outstanding-miss capacity delivers at ~2 us per access; a rank-16 update per trip is 2 flop per
-// byte, i.e. 21 % of the matrix peak at 640 - 1000 columns.  The request-ahead is worth 6 %, two pivot blocks per trip
-// 25 - 30 %; the register form removes the phase.)
+// (Measured, tools/ubench/inverse_rate.py: the phase runs at ~21 % of the matrix peak at 640 - 1000 columns whatever the
+// number of tiles per trip (2, 4), the issue order of stores and loads or the width of the tile loads; with 8 workgroups on
+// the chip it takes the same time with neither tile loads nor stores (-DINV_DIAG_NOLOAD -DINV_DIAG_NOSTORE: 3.77 vs 3.87 ms
+// at 640 columns), i.e. it is bound by the waves' own instruction streams; with 256 inverting at once memory comes on top
+// (6.7 vs 4.4 ms).  The request-ahead is worth 6 %, two pivot blocks per trip 25 - 30 %; the register form removes the
+// phase.  profiles/r03/inverse_ablation.txt)
 // timing-only ablations of the trailing update (tools/ubench/inverse_rate.py with a -DINV_DIAG_* build; results are wrong)
 #ifdef INV_DIAG_NOLOAD
 #define INV_DIAG_LOAD(expr, jc, ic) (1e-3 * (double)((jc) + (ic)))
