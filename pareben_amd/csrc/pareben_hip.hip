@@ -1217,13 +1217,21 @@ static int run_enqueue(pareben_ctx *c, int n_cells, const double *alpha, const d
 
     int occ = 1;
     const bool binom = c->prior == PAREBEN_PRIOR_BINOMIAL;
-    // Binomial launch shape.  Default: one 512-thread workgroup per CU with the whole LDS pool.  Two fits per CU as
-    // 256-thread workgroups with half the pool each (PAREBEN_BM_THREADS=256) were measured on config 3 and are no faster
-    // (282 vs 273 ms per grid): every step of a fit takes twice as many trips with half the threads, so the two resident
-    // fits each run at half speed.  PAREBEN_BM_POOL=<doubles> sets the pool (a build with -DBM_WAVES_PER_EU=4 needs two
-    // 512-thread workgroups to fit in one CU's LDS).
+    // Binomial launch shape.  Two fits per CU as 256-thread workgroups with half the LDS pool each when the launch has
+    // fits enough for that and a fold's samples allow the matrix-core paths in half a pool (N <= 512); else one 512-thread
+    // workgroup per CU with the whole pool.  A binomial fit is a chain of short phases in which three or four of the eight
+    // waves work while the rest stand at a barrier (63 % of the wave cycles wait: profiles/r03/pmc_extra_config3.txt); a second
+    // resident fit fills those gaps: config 3 205 -> 192 ms per grid.  (Measured early in round 3, when every phase still
+    // paid a memory round trip per element, the same shape was slower: 282 vs 273 ms.)  PAREBEN_BM_THREADS=512 | 256 forces a
+    // shape; PAREBEN_BM_POOL=<doubles> sets the pool (a build with -DBM_WAVES_PER_EU=4 needs two 512-thread workgroups to fit
+    // in one CU's LDS).  The reductions of a fit run over its own threads, so the last bits of a binomial result depend on the
+    // shape (not on anything else: same shape, same bits).
     int bm_threads = 512, bm_pool = LDS_POOL_DOUBLES;
-    if (const char *e = getenv("PAREBEN_BM_THREADS")) { if (atoi(e) == 256) { bm_threads = 256; bm_pool = BM_POOL_DOUBLES_HALF; } }
+    if (binom && n_units >= 2 * c->n_cu && c->BL.nmax <= 512) { bm_threads = 256; bm_pool = BM_POOL_DOUBLES_HALF; }
+    if (const char *e = getenv("PAREBEN_BM_THREADS")) {
+        if (atoi(e) == 256) { bm_threads = 256; bm_pool = BM_POOL_DOUBLES_HALF; }
+        else if (atoi(e) == 512) { bm_threads = 512; bm_pool = LDS_POOL_DOUBLES; }
+    }
     if (const char *e = getenv("PAREBEN_BM_POOL")) { const int v = atoi(e); if (v >= 4096 && v <= LDS_POOL_DOUBLES) bm_pool = v; }
     if (binom) {
         HIPCHK(hipFuncSetAttribute((const void *)bm_cv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_FOR(bm_pool)));
