@@ -89,22 +89,26 @@ DEV void bm_rows_dot(const Blk &NOALIAS B, const BmWork &NOALIAS W, int K, int M
 // The operand is addressed as a wave-uniform base (scalar registers) plus a 32-bit byte offset per lane (xo: the lane's
 // feature, xs: bytes between consecutive samples), the form in which the memory pipe takes a load at full rate; the
 // design is far below 4 GB.
+// [hlo, Nr): the samples of this call (hlo a multiple of 4; Nr the end of the range, a multiple of 4): the staged block and
+// the weights hold that range from index 0.  out / bbq_out come in with the values the chains start from (zero, or what an
+// earlier range of the same pass left: the chain simply goes on) and leave with the results.
 template <int NCT, int EXT>
-DEV void bm_wr_tile(gptr_cc xb, unsigned xo, unsigned xs, lptr_d zb, lptr_d lw, int pitch, int Nu, int Nr, int l4, double (&out)[NCT][4], double &bbq_out)
+DEV void bm_wr_tile(gptr_cc xb, unsigned xo, unsigned xs, lptr_d zb, lptr_d lw, int pitch, int Nu, int hlo, int Nr, int l4, double (&out)[NCT][4], double &bbq_out)
 {
     typedef double bd4 __attribute__((ext_vector_type(4)));
     constexpr int RS = 8;                                      // steps per round (16 measured: no difference, config 3 261 vs 260 ms)
     bd4 acc[NCT];
 #pragma unroll
-    for (int ct = 0; ct < NCT; ct++) acc[ct] = bd4{0, 0, 0, 0};
-    double bbq = 0;
+    for (int ct = 0; ct < NCT; ct++) acc[ct] = bd4{out[ct][0], out[ct][1], out[ct][2], out[ct][3]};
+    double bbq = bbq_out;
     double an[RS];
 #pragma unroll
-    for (int u = 0; u < RS; u++) { const int h = 4 * u + l4; an[u] = *(gptr_cd)(xb + (xo + (unsigned)(h < Nu ? h : Nu - 1) * xs)); }
+    for (int u = 0; u < RS; u++) { const int h = hlo + 4 * u + l4; an[u] = *(gptr_cd)(xb + (xo + (unsigned)(h < Nu ? h : Nu - 1) * xs)); }
     double bn[NCT];
 #pragma unroll
     for (int ct = 0; ct < NCT; ct++) bn[ct] = zb[ct * 16 * pitch];
-    for (int h0 = 0; h0 < Nr; h0 += 4 * RS) {
+    zb -= hlo; lw -= hlo;                                       // indexed by the absolute sample below
+    for (int h0 = hlo; h0 < Nr; h0 += 4 * RS) {
         double ac[RS];
 #pragma unroll
         for (int u = 0; u < RS; u++) ac[u] = (h0 + 4 * u + l4 < Nu) ? an[u] : 0.0;
@@ -163,6 +167,18 @@ DEVNI int bm_weighted_rows(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const
         const int Nr = (Nu + 3) & ~3, pitch = Nr + 1;
         int pcm = ((uni(B.pool_n) - (ws ? Nr : 0)) / pitch) & ~15;
         if (pcm > 16 * MAXCT) pcm = 16 * MAXCT;
+        // When the pool cannot hold all the columns of the pass over all the samples (half a pool: two fits per CU) the
+        // SAMPLES are cut into ranges rather than the columns into blocks: the design -- what the pass is bound by -- is
+        // still streamed once, the chains of a feature tile are parked in BP between two ranges (raw, exactly) and go on
+        // where they stopped.  nseg ranges of Hs samples.
+        const int want16 = (Mu + ws + 15) & ~15;
+        int nseg = 1, Hs = Nr;
+        if (want16 > pcm && want16 <= 16 * MAXCT && Mu + 8 <= ldu) {
+            while (nseg < 8 && want16 * (Hs + 1) + (ws ? Hs : 0) > uni(B.pool_n)) { nseg++; Hs = (((Nr + nseg - 1) / nseg) + 3) & ~3; }
+            if (want16 * (Hs + 1) + (ws ? Hs : 0) > uni(B.pool_n)) { nseg = 1; Hs = Nr; }
+            else pcm = want16;
+        }
+        const int pitch_s = nseg > 1 ? Hs + 1 : pitch;
         if (pcm >= 16) {
             const lptr_d Z = as_lds(uni_ptr(B.pool));          // [column][pitch]
             const gptr_cd gX = as_global(uni_ptr(F.X)), gw = as_global(uni_ptr(W.w)), ge = as_global(uni_ptr(W.e));
@@ -175,7 +191,10 @@ DEVNI int bm_weighted_rows(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const
                 const int ext = (ws && p0 == 0) ? 1 : 0;
                 const int pn = Mu - p0 < pcm - ext ? Mu - p0 : pcm - ext;
                 const int pn16 = (pn + ext + 15) & ~15, nct = pn16 >> 4;
-                const lptr_d lw = Z + pcm * pitch;                     // the weights, zero beyond the last sample
+                const lptr_d lw = Z + pcm * pitch_s;                   // the weights, zero beyond the last sample
+              for (int seg = 0; seg < nseg; seg++) {
+                const int hlo = seg * Hs, hhi = hlo + Hs < Nr ? hlo + Hs : Nr;     // this range of samples (all of them when nseg == 1)
+                const bool first = seg == 0, last = seg == nseg - 1;
                 blk_sync(B);
                 PHX_BEGIN(t_st);
                 // a wave per staged column: the column's feature id and norm are wave-uniform, the design column is read in
@@ -187,17 +206,17 @@ DEVNI int bm_weighted_rows(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const
                     const bool dvz = W.phi_div != 0;
                     const double sc = dvz ? gsc[u] : F.rscale[u];
                     const gptr_cd x = gX + (size_t)u * Nu;
-                    for (int h = lane; h < pitch; h += 64) {
-                        const int hc = h < Nu ? h : Nu - 1;
+                    for (int hl = lane; hl < pitch_s; hl += 64) {
+                        const int h = hlo + hl, hc = h < Nu ? h : Nu - 1;
                         double v = 0.0;
-                        if (h < Nu) {
+                        if (h < Nu && h < hhi) {
                             if (model) { const double xv = x[hc]; v = gw[hc] * (pm == 0 ? 1.0 : (dvz ? xv / sc : xv * sc)); }
                             else if (resid) v = ge[hc];
                         }
-                        Z[pc * pitch + h] = v;
+                        Z[pc * pitch_s + hl] = v;
                     }
                 }
-                if (ext) for (int h = tid; h < Nr; h += nthr) lw[h] = h < Nu ? gw[h] : 0.0;
+                if (ext) for (int hl = tid; hl < hhi - hlo; hl += nthr) lw[hl] = hlo + hl < Nu ? gw[hlo + hl] : 0.0;
                 blk_sync(B);
                 PHX_END(t_st, PH_HBUILD);
                 PHX_BEGIN(t_mm);
@@ -207,14 +226,28 @@ DEVNI int bm_weighted_rows(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const
                     const gptr_cc xb = (gptr_cc)(gXt ? gXt : gX);
                     const unsigned xo = gXt ? (unsigned)ilc * 8u : (unsigned)ilc * (unsigned)Nu * 8u;
                     const unsigned xs = gXt ? (unsigned)Ku * 8u : 8u;
-                    const lptr_d zb = Z + l15 * pitch + l4;
+                    const lptr_d zb = Z + l15 * pitch_s + l4;
                     double acc[MAXCT][4];
                     double bbq = 0;
+                    // where the chains of this tile are parked between two ranges: the BP entries themselves (raw sums), the
+                    // residual column in aroot, a lane's share of x' diag(w) x in the last four columns of the feature's row
+#pragma unroll
+                    for (int ct = 0; ct < MAXCT; ct++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            acc[ct][r] = 0.0;
+                            if (!first && ct < nct) {
+                                const int i = ft * 16 + l4 + 4 * r, col = ct * 16 + l15;
+                                if (i < Ku) { if (col < pn) acc[ct][r] = gBP[(size_t)i * ldu + p0 + col]; else if (ext && col == pn) acc[ct][r] = gze[i]; }
+                            }
+                        }
+                    if (!first && ext && il < Ku) bbq = gBP[(size_t)il * ldu + ldu - 4 + l4];
 #define BM_WR_CASE(n)                                                                                                   \
                     case n: {                                                                                           \
                         double o[n][4];                                                                                 \
-                        if (ext) bm_wr_tile<n, 1>(xb, xo, xs, zb, lw, pitch, Nu, Nr, l4, o, bbq);                       \
-                        else bm_wr_tile<n, 0>(xb, xo, xs, zb, lw, pitch, Nu, Nr, l4, o, bbq);                           \
+                        _Pragma("unroll") for (int ct = 0; ct < n; ct++) _Pragma("unroll") for (int r = 0; r < 4; r++) o[ct][r] = acc[ct][r]; \
+                        if (ext) bm_wr_tile<n, 1>(xb, xo, xs, zb, lw, pitch_s, Nu, hlo, hhi, l4, o, bbq);               \
+                        else bm_wr_tile<n, 0>(xb, xo, xs, zb, lw, pitch_s, Nu, hlo, hhi, l4, o, bbq);                   \
                         _Pragma("unroll") for (int ct = 0; ct < n; ct++) _Pragma("unroll") for (int r = 0; r < 4; r++) acc[ct][r] = o[ct][r]; \
                     } break;
                     switch (nct) { BM_WR_CASE(1) BM_WR_CASE(2) BM_WR_CASE(3) default: BM_WR_CASE(4) }
@@ -227,17 +260,21 @@ DEVNI int bm_weighted_rows(const Blk &NOALIAS B, const FoldDev &NOALIAS F, const
                         for (int r = 0; r < 4; r++) {
                             const int i = ft * 16 + l4 + 4 * r;
                             if (i < Ku) {
-                                if (col < pn) gBP[(size_t)i * ldu + p0 + col] = acc[ct][r] / gsc[i];
+                                if (col < pn) gBP[(size_t)i * ldu + p0 + col] = last ? acc[ct][r] / gsc[i] : acc[ct][r];
                                 else if (ext && col == pn) gze[i] = acc[ct][r];
                             }
                         }
                     }
-                    if (ext) {                                 // the four sample groups of a feature sit 16 lanes apart
-                        bbq += __shfl_xor(bbq, 16, 64); bbq += __shfl_xor(bbq, 32, 64);
-                        if (l4 == 0 && il < Ku) gbb[il] = bbq;
+                    if (ext) {
+                        if (!last) { if (il < Ku) gBP[(size_t)il * ldu + ldu - 4 + l4] = bbq; }
+                        else {                                 // the four sample groups of a feature sit 16 lanes apart
+                            bbq += __shfl_xor(bbq, 16, 64); bbq += __shfl_xor(bbq, 32, 64);
+                            if (l4 == 0 && il < Ku) gbb[il] = bbq;
+                        }
                     }
                 }
                 PHX_END(t_mm, PH_MATVEC);
+              }
                 p0 += pn;
             }
             blk_sync(B);
