@@ -241,6 +241,31 @@ def test_binomial_config3_full_grid_vs_golden(golden):
     assert abs(np.asarray(S["SE"])[i] - k["SE"]) < 1e-6 * k["SE"]
 
 
+def test_binomial_launch_shapes(golden, monkeypatch):
+    """The binomial CV launch runs two 256-thread fits per CU when it has fits enough (config 3: 2000 fits), else one
+    512-thread fit per CU; PAREBEN_BM_THREADS forces a shape.  A fit's reductions run over its own threads, so the two
+    shapes may differ in the last bits -- and in nothing else: each shape repeats itself bit for bit, the two agree to 1e-10
+    (the oracle table is 1e-8 away from either: test_binomial_config3_full_grid_vs_golden runs the default shape) and pick
+    the same optimum."""
+    X, y = golden.BASISbinomial, golden.yBinomial
+    fid = AssignToFolds(X, 5)
+    alpha, lam = BuildGrid(X, y, 5)
+    runs = {}
+    with pareben_amd.Context(X, y, fid, 5, prior="binomial") as ctx:
+        for shape in ("256", "256", "512", "512"):
+            monkeypatch.setenv("PAREBEN_BM_THREADS", shape)
+            E, st, _ = ctx.run(alpha, lam)
+            assert ctx.launch_info()["threads"] == int(shape) and np.all(st & 8 == 0)
+            if shape in runs:
+                assert np.array_equal(runs[shape], E)
+            runs[shape] = E
+        monkeypatch.delenv("PAREBEN_BM_THREADS")
+        E, st, _ = ctx.run(alpha, lam)
+        assert ctx.launch_info()["threads"] == 256 and np.array_equal(E, runs["256"])      # the default for a launch of this size
+    assert np.abs(runs["256"] - runs["512"]).max() < 1e-10
+    assert int(np.argmin(runs["256"].mean(axis=1))) == int(np.argmin(runs["512"].mean(axis=1)))
+
+
 def test_binomial_synthetic_vs_oracle(oracle):
     rng = np.random.default_rng(9)
     X = np.asfortranarray(rng.standard_normal((123, 77)))
